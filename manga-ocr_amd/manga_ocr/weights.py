@@ -1,0 +1,270 @@
+"""Model specification and weight sources for the Manga-OCR recogniser.
+
+The recogniser the reference calls at ``src/ui/main_window.py:9801`` is a
+VisionEncoderDecoder model: ViT-B/16-224 encoder + 2-layer BERT decoder with
+cross-attention.  This module owns
+
+* ``ModelSpec``       - the hyper-parameters (fixed by BASELINE.json),
+* ``tensor_table()``  - every parameter tensor the engine consumes, by its
+                        canonical (transformers-5.x state_dict) name,
+* ``synthetic_weights()`` - the deterministic synthetic weights used by every
+                        pinned test and by bench.py (no checkpoint is available
+                        offline),
+* ``load_checkpoint()``   - loader for a local HF ``model_dir`` (4.x or 5.x key
+                        spelling, ``TF/conversion_mapping.py:338-346``).
+
+Weights are plain ``dict[str, np.ndarray(float32)]``; nothing here touches a GPU.
+"""
+from __future__ import annotations
+
+import json
+import os
+import re
+from dataclasses import dataclass, asdict
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+
+@dataclass(frozen=True)
+class ModelSpec:
+    image_size: int = 224
+    patch_size: int = 16
+    hidden: int = 768          # encoder == decoder width, so no enc_to_dec_proj
+    enc_layers: int = 12
+    dec_layers: int = 2
+    heads: int = 12
+    ffn: int = 3072
+    vocab: int = 6144
+    max_pos: int = 512         # decoder position table
+    type_vocab: int = 2
+    ln_eps: float = 1e-12
+    max_len: int = 300         # generate(max_length=300)
+    start_id: int = 2          # [CLS] = decoder_start_token_id
+    eos_id: int = 3            # [SEP]
+    pad_id: int = 0            # [PAD]
+
+    @property
+    def grid(self) -> int:
+        return self.image_size // self.patch_size
+
+    @property
+    def n_patches(self) -> int:
+        return self.grid * self.grid
+
+    @property
+    def enc_tokens(self) -> int:
+        return self.n_patches + 1
+
+    @property
+    def head_dim(self) -> int:
+        return self.hidden // self.heads
+
+    def to_dict(self) -> dict:
+        return asdict(self)
+
+
+DEFAULT_SPEC = ModelSpec()
+
+# kind: 'w' dense weight / embedding table, 'b' bias, 'g' LayerNorm gain, 'beta' LayerNorm shift
+TensorRow = Tuple[str, Tuple[int, ...], str]
+
+
+def tensor_table(spec: ModelSpec = DEFAULT_SPEC) -> List[TensorRow]:
+    """Ordered list of (canonical name, shape, kind).  The ORDER is part of the
+    synthetic-weight definition: tensors are drawn from one RandomState stream in
+    exactly this order."""
+    D, F, V = spec.hidden, spec.ffn, spec.vocab
+    P = spec.patch_size
+    rows: List[TensorRow] = []
+    add = rows.append
+    e = "encoder."
+    add((e + "embeddings.cls_token", (1, 1, D), "w"))
+    add((e + "embeddings.position_embeddings", (1, spec.enc_tokens, D), "w"))
+    add((e + "embeddings.patch_embeddings.projection.weight", (D, 3, P, P), "w"))
+    add((e + "embeddings.patch_embeddings.projection.bias", (D,), "b"))
+    for i in range(spec.enc_layers):
+        p = f"{e}layers.{i}."
+        for n in ("q_proj", "k_proj", "v_proj", "o_proj"):
+            add((p + f"attention.{n}.weight", (D, D), "w"))
+            add((p + f"attention.{n}.bias", (D,), "b"))
+        add((p + "layernorm_before.weight", (D,), "g"))
+        add((p + "layernorm_before.bias", (D,), "beta"))
+        add((p + "layernorm_after.weight", (D,), "g"))
+        add((p + "layernorm_after.bias", (D,), "beta"))
+        add((p + "mlp.fc1.weight", (F, D), "w"))
+        add((p + "mlp.fc1.bias", (F,), "b"))
+        add((p + "mlp.fc2.weight", (D, F), "w"))
+        add((p + "mlp.fc2.bias", (D,), "b"))
+    add((e + "layernorm.weight", (D,), "g"))
+    add((e + "layernorm.bias", (D,), "beta"))
+    d = "decoder.bert."
+    add((d + "embeddings.word_embeddings.weight", (V, D), "w"))
+    add((d + "embeddings.position_embeddings.weight", (spec.max_pos, D), "w"))
+    add((d + "embeddings.token_type_embeddings.weight", (spec.type_vocab, D), "w"))
+    add((d + "embeddings.LayerNorm.weight", (D,), "g"))
+    add((d + "embeddings.LayerNorm.bias", (D,), "beta"))
+    for i in range(spec.dec_layers):
+        p = f"{d}encoder.layer.{i}."
+        for blk in ("attention", "crossattention"):
+            for n in ("query", "key", "value"):
+                add((p + f"{blk}.self.{n}.weight", (D, D), "w"))
+                add((p + f"{blk}.self.{n}.bias", (D,), "b"))
+            add((p + f"{blk}.output.dense.weight", (D, D), "w"))
+            add((p + f"{blk}.output.dense.bias", (D,), "b"))
+            add((p + f"{blk}.output.LayerNorm.weight", (D,), "g"))
+            add((p + f"{blk}.output.LayerNorm.bias", (D,), "beta"))
+        add((p + "intermediate.dense.weight", (F, D), "w"))
+        add((p + "intermediate.dense.bias", (F,), "b"))
+        add((p + "output.dense.weight", (D, F), "w"))
+        add((p + "output.dense.bias", (D,), "b"))
+        add((p + "output.LayerNorm.weight", (D,), "g"))
+        add((p + "output.LayerNorm.bias", (D,), "beta"))
+    c = "decoder.cls.predictions."
+    add((c + "transform.dense.weight", (D, D), "w"))
+    add((c + "transform.dense.bias", (D,), "b"))
+    add((c + "transform.LayerNorm.weight", (D,), "g"))
+    add((c + "transform.LayerNorm.bias", (D,), "beta"))
+    # The vocabulary projection.  HF ties it to the word embeddings when
+    # tie_word_embeddings is set (TF/models/bert/modeling_bert.py:825-828); the engine
+    # always receives it as its own tensor.
+    add((c + "decoder.weight", (V, D), "w"))
+    add((c + "decoder.bias", (V,), "b"))
+    return rows
+
+
+def synthetic_weights(seed: int = 0, spec: ModelSpec = DEFAULT_SPEC, *, std: float = 0.02,
+                      bias_std: float = 0.02, ln_std: float = 0.1, tie_lm_head: bool = True,
+                      eos_bias: float = 0.0, logit_scale: float = 1.0) -> Dict[str, np.ndarray]:
+    """Deterministic synthetic parameters (float32).
+
+    One ``numpy.random.RandomState(seed)`` stream (frozen algorithm), tensors drawn
+    in ``tensor_table`` order with ``standard_normal(shape)``:
+      'w'    -> std * z            'b'    -> bias_std * z
+      'g'    -> 1 + ln_std * z     'beta' -> ln_std * z
+    Biases and LayerNorm parameters are deliberately non-trivial so that a kernel
+    which drops one fails parity.  ``tie_lm_head`` copies the word-embedding table
+    into the vocabulary projection after drawing (the draw still happens, so the
+    stream position of later tensors does not depend on the flag).
+    ``eos_bias`` is added to the vocabulary bias of ``eos_id`` (makes rows finish at
+    different steps: exercises the finished-row padding rule).  ``logit_scale``
+    multiplies the vocabulary projection weight (widens top-1 margins so that a
+    bf16 engine's token ids are comparable with the fp32 oracle's).
+    """
+    rs = np.random.RandomState(seed)
+    out: Dict[str, np.ndarray] = {}
+    for name, shape, kind in tensor_table(spec):
+        z = rs.standard_normal(shape)
+        if kind == "w":
+            a = std * z
+        elif kind == "b":
+            a = bias_std * z
+        elif kind == "g":
+            a = 1.0 + ln_std * z
+        elif kind == "beta":
+            a = ln_std * z
+        else:  # pragma: no cover
+            raise ValueError(kind)
+        out[name] = np.ascontiguousarray(a, dtype=np.float32)
+    lm_w = "decoder.cls.predictions.decoder.weight"
+    lm_b = "decoder.cls.predictions.decoder.bias"
+    if tie_lm_head:
+        out[lm_w] = out["decoder.bert.embeddings.word_embeddings.weight"].copy()
+    if logit_scale != 1.0:
+        out[lm_w] = (out[lm_w] * np.float32(logit_scale)).astype(np.float32)
+    if eos_bias != 0.0:
+        out[lm_b] = out[lm_b].copy()
+        out[lm_b][spec.eos_id] += np.float32(eos_bias)
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# Real checkpoints (a local HF model_dir; never fetched - there is no network)
+# --------------------------------------------------------------------------------------
+
+_V4_TO_V5 = [  # transformers-4.x ViT spelling -> 5.x (TF/conversion_mapping.py:338-346)
+    (r"^encoder\.encoder\.layer\.(\d+)\.attention\.attention\.query\.", r"encoder.layers.\1.attention.q_proj."),
+    (r"^encoder\.encoder\.layer\.(\d+)\.attention\.attention\.key\.", r"encoder.layers.\1.attention.k_proj."),
+    (r"^encoder\.encoder\.layer\.(\d+)\.attention\.attention\.value\.", r"encoder.layers.\1.attention.v_proj."),
+    (r"^encoder\.encoder\.layer\.(\d+)\.attention\.output\.dense\.", r"encoder.layers.\1.attention.o_proj."),
+    (r"^encoder\.encoder\.layer\.(\d+)\.intermediate\.dense\.", r"encoder.layers.\1.mlp.fc1."),
+    (r"^encoder\.encoder\.layer\.(\d+)\.output\.dense\.", r"encoder.layers.\1.mlp.fc2."),
+    (r"^encoder\.encoder\.layer\.(\d+)\.layernorm_", r"encoder.layers.\1.layernorm_"),
+]
+
+
+def canonical_name(key: str) -> str:
+    for pat, rep in _V4_TO_V5:
+        new = re.sub(pat, rep, key)
+        if new != key:
+            return new
+    return key
+
+
+def spec_from_hf_config(cfg: dict) -> ModelSpec:
+    """Build a ModelSpec from a VisionEncoderDecoder ``config.json`` dict, asserting the
+    structural assumptions the kernels make instead of assuming them."""
+    enc, dec = cfg["encoder"], cfg["decoder"]
+    if enc.get("hidden_size", 768) != dec.get("hidden_size", 768):
+        raise ValueError("encoder/decoder widths differ: enc_to_dec_proj is not supported")
+    for side, c in (("encoder", enc), ("decoder", dec)):
+        if c.get("hidden_act", "gelu") != "gelu":
+            raise ValueError(f"{side} hidden_act must be exact-erf 'gelu'")
+    if enc.get("num_attention_heads", 12) != dec.get("num_attention_heads", 12):
+        raise ValueError("encoder/decoder head counts differ")
+    spec = ModelSpec(
+        image_size=enc.get("image_size", 224), patch_size=enc.get("patch_size", 16),
+        hidden=enc.get("hidden_size", 768), enc_layers=enc.get("num_hidden_layers", 12),
+        dec_layers=dec.get("num_hidden_layers", 2), heads=enc.get("num_attention_heads", 12),
+        ffn=enc.get("intermediate_size", 3072), vocab=dec["vocab_size"],
+        max_pos=dec.get("max_position_embeddings", 512), type_vocab=dec.get("type_vocab_size", 2),
+        ln_eps=float(enc.get("layer_norm_eps", 1e-12)),
+        max_len=int(cfg.get("max_length", dec.get("max_length", 300)) or 300),
+        start_id=int(cfg.get("decoder_start_token_id", 2)),
+        eos_id=int(cfg.get("eos_token_id", dec.get("eos_token_id", 3)) or 3),
+        pad_id=int(cfg.get("pad_token_id", dec.get("pad_token_id", 0)) or 0),
+    )
+    if float(dec.get("layer_norm_eps", 1e-12)) != spec.ln_eps:
+        raise ValueError("encoder/decoder layer_norm_eps differ")
+    if dec.get("intermediate_size", 3072) != spec.ffn:
+        raise ValueError("encoder/decoder FFN widths differ")
+    for k in ("num_beams",):
+        if int(cfg.get(k, dec.get(k, 1)) or 1) != 1:
+            raise ValueError("checkpoint asks for beam search; the engine implements greedy decode only")
+    return spec
+
+
+def load_checkpoint(model_dir: str) -> Tuple[ModelSpec, Dict[str, np.ndarray]]:
+    """Read ``config.json`` + ``model.safetensors`` (or ``pytorch_model.bin``) from a local
+    directory and return (spec, canonical float32 weights)."""
+    with open(os.path.join(model_dir, "config.json"), "r", encoding="utf-8") as f:
+        cfg = json.load(f)
+    spec = spec_from_hf_config(cfg)
+    raw: Dict[str, np.ndarray] = {}
+    st = os.path.join(model_dir, "model.safetensors")
+    if os.path.exists(st):
+        from safetensors.numpy import load_file
+        raw = {k: np.asarray(v) for k, v in load_file(st).items()}
+    else:
+        import torch
+        sd = torch.load(os.path.join(model_dir, "pytorch_model.bin"), map_location="cpu", weights_only=True)
+        raw = {k: v.float().numpy() for k, v in sd.items()}
+    w = {canonical_name(k): np.ascontiguousarray(v, dtype=np.float32) for k, v in raw.items()}
+    lm_w = "decoder.cls.predictions.decoder.weight"
+    lm_b = "decoder.cls.predictions.decoder.bias"
+    if lm_w not in w:  # tied head
+        w[lm_w] = w["decoder.bert.embeddings.word_embeddings.weight"].copy()
+    if lm_b not in w:
+        w[lm_b] = w["decoder.cls.predictions.bias"]
+    check_weights(w, spec)
+    return spec, w
+
+
+def check_weights(w: Dict[str, np.ndarray], spec: ModelSpec = DEFAULT_SPEC) -> None:
+    for name, shape, _ in tensor_table(spec):
+        if name not in w:
+            raise KeyError(f"missing tensor {name}")
+        if tuple(w[name].shape) != tuple(shape):
+            raise ValueError(f"{name}: shape {tuple(w[name].shape)} != {tuple(shape)}")
+        if w[name].dtype != np.float32:
+            raise TypeError(f"{name}: dtype {w[name].dtype} != float32")
