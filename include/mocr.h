@@ -1,0 +1,147 @@
+/*
+ * mocr.h - C ABI of the MI355X-native Manga-OCR recogniser engine (libmocr_hip.so).
+ *
+ * This is the drop-in boundary for ONE call of the reference application:
+ *
+ *     raw_text = self.manga_ocr_reader(pil_img)          reference src/ui/main_window.py:9801
+ *
+ * i.e. `manga_ocr.MangaOcr.__call__(PIL.Image) -> str`, constructed once at
+ * src/ui/main_window.py:3394 (`MangaOcr()`), imported at src/core/config.py:431-436 and
+ * called concurrently, without a lock, by up to MAX_WORKERS QueueProcessorWorker threads
+ * (src/core/workers.py:209-247, 318-327, 383-402) and by the text-detect path
+ * (src/ui/main_window.py:9462-9476, 9530-9549).  The reference has no native interface of
+ * its own (it is pure Python); the entry points below are what a binding for that call
+ * needs, and the Python class manga_ocr.MangaOcr in this repo is that binding (ctypes).
+ * INTEGRATION.md shows the stub.
+ *
+ * Conventions: plain C, no exceptions, no Python or torch types.  Every function returns
+ * MOCR_OK (0) or a negative error code; mocr_last_error() returns a message for the last
+ * failure on that engine.  The caller owns every buffer it passes.  Token-id blocks are
+ * int32, row-major [n, max_len]; a row holds start_id, the generated ids, eos_id, then
+ * pad_id up to max_len - exactly the rows `generate(max_length=max_len)` returns
+ * (TF/generation/utils.py:2929-2937), padded to the fixed width.
+ */
+#ifndef MOCR_H
+#define MOCR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MOCR_ABI_VERSION 1
+
+enum {
+    MOCR_OK = 0,
+    MOCR_ERR_ARG = -1,          /* bad argument (null, size, unsupported shape) */
+    MOCR_ERR_STATE = -2,        /* call order (weights not committed, ...) */
+    MOCR_ERR_HIP = -3,          /* a HIP runtime call failed */
+    MOCR_ERR_UNSUPPORTED = -4,  /* valid request this build does not implement */
+    MOCR_ERR_NOMEM = -5
+};
+
+enum { MOCR_F32 = 0, MOCR_BF16 = 1 };
+
+/* mocr_config.flags */
+enum {
+    MOCR_FLAG_SIMPLE_ATTENTION = 1 << 0, /* encoder attention on the VALU kernel even in bf16 mode */
+    MOCR_FLAG_NO_GRAPH = 1 << 1,         /* launch decode steps eagerly instead of replaying a HIP graph */
+    MOCR_FLAG_NO_EARLY_EXIT = 1 << 2     /* always run max_len-1 decode steps */
+};
+
+typedef struct mocr_engine mocr_engine;
+
+/* Replaces the (argument-less) constructor call at src/ui/main_window.py:3394.  The model
+ * hyper-parameters are those BASELINE.json fixes (ViT-B/16-224 + 2-layer BERT decoder). */
+typedef struct mocr_config {
+    int32_t struct_size; /* sizeof(mocr_config), for forward compatibility */
+    int32_t device;      /* HIP device ordinal of this process's GPU */
+    int32_t dtype;       /* MOCR_F32 (parity mode) or MOCR_BF16 (bf16 storage, fp32 accumulate) */
+    int32_t max_batch;   /* crops per internal batch (rows of one decode step) */
+    int32_t max_len;     /* generate(max_length): 300 */
+    int32_t image_size;  /* 224 */
+    int32_t patch_size;  /* 16 */
+    int32_t hidden;      /* 768 */
+    int32_t enc_layers;  /* 12 */
+    int32_t dec_layers;  /* 2 */
+    int32_t heads;       /* 12 */
+    int32_t ffn;         /* 3072 */
+    int32_t vocab;       /* 6144 */
+    int32_t max_pos;     /* 512 */
+    int32_t start_id;    /* 2 */
+    int32_t eos_id;      /* 3 */
+    int32_t pad_id;      /* 0 */
+    float ln_eps;        /* 1e-12 */
+    int32_t flags;
+} mocr_config;
+
+int mocr_abi_version(void);
+
+/* Construct an engine on cfg->device.  Allocates all device memory for max_batch. */
+int mocr_create(const mocr_config* cfg, mocr_engine** out);
+void mocr_destroy(mocr_engine* e);
+const char* mocr_last_error(const mocr_engine* e);
+
+/* Weights: one call per tensor of the model (canonical transformers-5.x state_dict names,
+ * e.g. "encoder.layers.0.attention.q_proj.weight"), host float32, row-major; then commit.
+ * Replaces the `from_pretrained(...)` inside the reference's recogniser constructor. */
+int mocr_set_tensor(mocr_engine* e, const char* name, const float* data, const int64_t* shape, int32_t ndim);
+int mocr_commit_weights(mocr_engine* e);
+
+/* THE HOT PATH (host buffers).  images: n crops, uint8, each h x w with `channels` (1 = the
+ * luminance plane the recogniser's convert('L') would produce, 3 = RGB as handed over at
+ * src/ui/main_window.py:9800; converted on the device with Pillow's fixed-point formula),
+ * row_stride bytes between rows, image_stride bytes between crops.  h and w must equal
+ * image_size (the PIL-exact resize of other sizes is done by the caller in this version).
+ * out_ids [n, max_len] int32, out_len [n] int32.  Blocking; thread-safe (calls from
+ * several threads are serialised per engine).  n may exceed max_batch. */
+int mocr_recognize(mocr_engine* e, const uint8_t* images, int32_t n, int32_t h, int32_t w,
+                   int64_t row_stride, int64_t image_stride, int32_t channels,
+                   int32_t* out_ids, int32_t* out_len);
+
+/* THE HOT PATH (device buffers, asynchronous): d_gray is a device pointer to n contiguous
+ * image_size x image_size uint8 luminance planes, d_out_ids / d_out_len device pointers
+ * ([n,max_len] / [n] int32), n <= max_batch.  Work is enqueued on the engine's stream
+ * (mocr_stream()); call mocr_synchronize() before reading the outputs. */
+int mocr_recognize_device(mocr_engine* e, const void* d_gray, int32_t n, void* d_out_ids, void* d_out_len);
+int mocr_synchronize(mocr_engine* e);
+/* The hipStream_t the engine launches on (so a caller can order its own work / events). */
+void* mocr_stream(mocr_engine* e);
+
+/* ---- test hooks (fp32 out; used by tests/ and __graft_entry__.smoke()) -------------------- */
+/* Encoder only: h_out [n, 197, hidden] float32 (final LayerNorm output). */
+int mocr_encode(mocr_engine* e, const void* d_gray, int32_t n, float* h_out);
+/* Teacher-forced decode: inputs forced_ids [n, T] (forced_ids[:,0] must be start_id);
+ * h_logits [n, T, vocab] float32 = logits after consuming forced_ids[:, :t+1]. */
+int mocr_decode_logits(mocr_engine* e, const void* d_gray, int32_t n, const int32_t* forced_ids,
+                       int32_t T, float* h_logits);
+/* Greedy decode limited to max_len_override tokens (<= max_len); host outputs. */
+int mocr_recognize_gray_host(mocr_engine* e, const uint8_t* gray, int32_t n, int32_t max_len_override,
+                             int32_t* out_ids, int32_t* out_len);
+
+/* Single operators on device buffers of the engine's dtype (kernel unit tests). */
+int mocr_op_gemm(mocr_engine* e, const void* dA, const void* dW, const float* d_bias, void* d_out,
+                 const float* d_resid, int32_t M, int32_t N, int32_t K, int32_t epilogue,
+                 int32_t tile, int32_t split_k);
+int mocr_op_layernorm(mocr_engine* e, const float* d_x, const float* d_gamma, const float* d_beta,
+                      void* d_out, int32_t M);
+int mocr_op_enc_attention(mocr_engine* e, const void* d_qkv, void* d_ctx, int32_t n, int32_t impl);
+
+/* ---- per-kernel timing (HIP events on the engine's stream) -------------------------------- */
+typedef struct mocr_kernel_stat {
+    char name[48];
+    int64_t launches;
+    double total_ms;     /* sum of event-measured durations */
+    double flops;        /* algorithmic FLOPs over those launches (2 per MAC) */
+    double bytes;        /* algorithmic HBM bytes over those launches */
+} mocr_kernel_stat;
+
+int mocr_profile_enable(mocr_engine* e, int32_t on); /* on: record an event pair around every launch */
+int mocr_profile_reset(mocr_engine* e);
+int mocr_profile_get(mocr_engine* e, mocr_kernel_stat* out, int32_t cap, int32_t* n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOCR_H */

@@ -1,0 +1,85 @@
+// Shared device/host helpers for the Manga-OCR MI355X engine (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned short bf16_t;  // raw bfloat16 bits
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define MOCR_WAVE 64
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN
+    return *reinterpret_cast<bf16_t*>(&b);
+}
+
+// ---- typed element access: T is float (parity mode) or bf16_t (bf16 storage) ------------------
+template <typename T> struct elem;
+template <> struct elem<float> {
+    static __device__ __forceinline__ float ld(const float* p) { return *p; }
+    static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+    static __device__ __forceinline__ void ld4(const float* p, float* o) {
+        float4 v = *reinterpret_cast<const float4*>(p);
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    }
+    static __device__ __forceinline__ void st4(float* p, const float* v) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    static __device__ __forceinline__ void ld8(const float* p, float* o) { ld4(p, o); ld4(p + 4, o + 4); }
+    static __device__ __forceinline__ void st8(float* p, const float* v) { st4(p, v); st4(p + 4, v + 4); }
+};
+template <> struct elem<bf16_t> {
+    static __device__ __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+    static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+    static __device__ __forceinline__ void ld4(const bf16_t* p, float* o) {
+        uint2 v = *reinterpret_cast<const uint2*>(p);
+        o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+        o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+    }
+    static __device__ __forceinline__ void st4(bf16_t* p, const float* v) {
+        uint2 u;
+        u.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+        u.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+        *reinterpret_cast<uint2*>(p) = u;
+    }
+    static __device__ __forceinline__ void ld8(const bf16_t* p, float* o) {
+        uint4 v = *reinterpret_cast<const uint4*>(p);
+        o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+        o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+        o[4] = __uint_as_float(v.z << 16); o[5] = __uint_as_float(v.z & 0xffff0000u);
+        o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xffff0000u);
+    }
+    static __device__ __forceinline__ void st8(bf16_t* p, const float* v) {
+        uint4 u;
+        u.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+        u.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+        u.z = (unsigned)f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16);
+        u.w = (unsigned)f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16);
+        *reinterpret_cast<uint4*>(p) = u;
+    }
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// exact-erf GELU (hidden_act="gelu"): 0.5 x (1 + erf(x / sqrt(2)))
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// Async global -> LDS copy, 16 bytes per lane.  `lds_wave_base` must be wave-uniform: the
+// hardware writes lane i's 16 bytes at lds_wave_base + 16*i (cdna_hip_programming.md §5).
+__device__ __forceinline__ void glds16(const void* gsrc_lane, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}

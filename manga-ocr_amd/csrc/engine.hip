@@ -1,0 +1,880 @@
+// libmocr_hip.so - engine and C ABI (include/mocr.h) of the MI355X-native Manga-OCR recogniser.
+//
+// Data flow of one batch of n crops (M = n * 197 encoder rows), all buffers resident in HBM:
+//
+//   gray u8 [n,224,224] --patchify--> Ape T[n*196,256] --GEMM+bias+pos--> X f32 [M,768]   (CLS rows apart)
+//   12 x { LN(X)->Xn T ; QKV GEMM ->QKV T[M,2304] ; attention -> CTX T[M,768] ; O GEMM + resid -> X ;
+//          LN(X)->Xn ; FC1 GEMM+GELU -> Hb T[M,3072] ; FC2 GEMM + resid -> X }
+//   LN(X) -> ENC T[M,768] ; cross-K/V GEMM (both decoder layers at once) -> CKV T[M, 2*2*768]
+//   greedy loop, <= max_len-1 steps over n rows: see decode_step().
+//
+// The residual stream X is fp32 in both modes; T is the storage type of GEMM operands
+// (bf16 or fp32).  Decode-step projections (M = n) are split-K GEMMs writing fp32 partial slabs.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/mocr.h"
+#include "common.h"
+#include "kernels_attn.h"
+#include "kernels_decode.h"
+#include "kernels_gemm.h"
+#include "kernels_misc.h"
+
+namespace {
+
+struct HipError { hipError_t code; const char* what; int line; };
+#define HIPCHECK(x)                                             \
+    do {                                                        \
+        hipError_t err__ = (x);                                 \
+        if (err__ != hipSuccess) throw HipError{err__, #x, __LINE__}; \
+    } while (0)
+struct ArgError { std::string msg; int code; };
+
+static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+static inline uint16_t host_f2bf(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+struct EncLayerW {
+    void *wqkv, *wo, *w1, *w2;
+    float *bqkv, *bo, *b1, *b2, *ln1g, *ln1b, *ln2g, *ln2b;
+};
+struct DecLayerW {
+    void *wqkv, *wo, *wqc, *woc, *w1, *w2;
+    float *bqkv, *bo, *bqc, *boc, *b1, *b2, *ln1g, *ln1b, *ln2g, *ln2b, *ln3g, *ln3b;
+};
+struct Weights {
+    void* wpe = nullptr; float *bpe = nullptr, *cls = nullptr, *pos_enc = nullptr;
+    std::vector<EncLayerW> enc;
+    float *lnfg = nullptr, *lnfb = nullptr;
+    void* wckv = nullptr; float* bckv = nullptr;
+    float *word = nullptr, *posd = nullptr, *type0 = nullptr, *embg = nullptr, *embb = nullptr;
+    std::vector<DecLayerW> dec;
+    void* wt = nullptr; float *bt = nullptr, *lntg = nullptr, *lntb = nullptr;
+    void* wv = nullptr; float* bv = nullptr;
+    float* lut = nullptr;
+};
+
+struct ProfRec { int kid; hipEvent_t e0, e1; double flops, bytes; };
+
+}  // namespace
+
+struct mocr_engine {
+    mocr_config cfg{};
+    std::string err;
+    std::mutex mu;
+    hipStream_t stream = nullptr;
+    bool committed = false;
+    std::map<std::string, std::vector<float>> host_w;
+    std::map<std::string, std::vector<int64_t>> host_shape;
+    std::vector<void*> allocs;
+    Weights w;
+    // geometry
+    int S = 0, G = 0, D = 0, H = 0, F = 0, V = 0, Bp = 0, Mp = 0, NCKV = 0;
+    size_t esz = 2;
+    // workspace
+    uint8_t *d_in = nullptr, *d_rgb = nullptr;
+    float* X = nullptr;
+    void *Xn = nullptr, *QKV = nullptr, *CTX = nullptr, *Hb = nullptr, *ENC = nullptr, *CKV = nullptr;
+    void *kcache = nullptr, *vcache = nullptr;     // [dec_layers][Bp][H][max_len][64]
+    float* slabs = nullptr; long long slab_cap = 0; // floats
+    float *x_f32 = nullptr, *a_f32 = nullptr, *c_f32 = nullptr;
+    void *x_t = nullptr, *a_t = nullptr, *c_t = nullptr, *ctx_t = nullptr, *h_t = nullptr, *z_t = nullptr;
+    int *ids = nullptr, *step = nullptr, *finished = nullptr, *len = nullptr, *n_unf = nullptr;
+    int* forced = nullptr; float* logits_dbg = nullptr; size_t forced_cap = 0, logits_cap = 0;
+    int* h_pinned = nullptr;
+    // profiling
+    bool prof_on = false;
+    std::vector<std::string> knames;
+    std::vector<ProfRec> recs;
+    std::vector<hipEvent_t> ev_pool;
+    std::vector<mocr_kernel_stat> stats;
+
+    template <typename X_> X_* dalloc(size_t count) {
+        void* p = nullptr;
+        HIPCHECK(hipMalloc(&p, std::max<size_t>(count * sizeof(X_), 256)));
+        HIPCHECK(hipMemset(p, 0, std::max<size_t>(count * sizeof(X_), 256)));
+        allocs.push_back(p);
+        return reinterpret_cast<X_*>(p);
+    }
+    int kid(const char* name) {
+        for (size_t i = 0; i < knames.size(); ++i)
+            if (knames[i] == name) return (int)i;
+        knames.push_back(name);
+        mocr_kernel_stat s{};
+        snprintf(s.name, sizeof(s.name), "%s", name);
+        stats.push_back(s);
+        return (int)knames.size() - 1;
+    }
+    hipEvent_t get_event() {
+        if (!ev_pool.empty()) { hipEvent_t e = ev_pool.back(); ev_pool.pop_back(); return e; }
+        hipEvent_t e; HIPCHECK(hipEventCreate(&e)); return e;
+    }
+    void prof_begin(const char* name, double flops, double bytes) {
+        if (!prof_on) return;
+        ProfRec r{kid(name), get_event(), get_event(), flops, bytes};
+        HIPCHECK(hipEventRecord(r.e0, stream));
+        recs.push_back(r);
+    }
+    void prof_end() {
+        if (!prof_on) return;
+        HIPCHECK(hipEventRecord(recs.back().e1, stream));
+    }
+    void prof_collect() {
+        if (recs.empty()) return;
+        HIPCHECK(hipStreamSynchronize(stream));
+        for (auto& r : recs) {
+            float ms = 0.f;
+            HIPCHECK(hipEventElapsedTime(&ms, r.e0, r.e1));
+            auto& s = stats[r.kid];
+            s.launches += 1; s.total_ms += ms; s.flops += r.flops; s.bytes += r.bytes;
+            ev_pool.push_back(r.e0); ev_pool.push_back(r.e1);
+        }
+        recs.clear();
+    }
+};
+
+namespace {
+
+struct ProfScope {
+    mocr_engine* e;
+    ProfScope(mocr_engine* e_, const char* name, double flops, double bytes) : e(e_) { e->prof_begin(name, flops, bytes); }
+    ~ProfScope() { e->prof_end(); }
+};
+
+template <typename K> void set_max_lds(K kernel, int bytes) {
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+}
+
+// ---------------------------------------------------------------------------------------- GEMM
+template <typename T, int BM, int BN, int EPI>
+void launch_gemm_t(mocr_engine* e, const GemmParams& p0, int split) {
+    GemmParams p = p0;
+    p.ntn = p.N / BN;
+    const int ntm = (p.M + BM - 1) / BM;
+    constexpr int lds = 2 * (BM + BN) * 128;
+    static bool once = false;
+    if (!once) { set_max_lds(gemm_kernel<T, BM, BN, EPI>, lds); once = true; }
+    dim3 grid(ntm * p.ntn, 1, split);
+    hipLaunchKernelGGL((gemm_kernel<T, BM, BN, EPI>), grid, dim3(256), lds, e->stream, p);
+    HIPCHECK(hipGetLastError());
+}
+
+template <typename T, int BM, int BN>
+void launch_gemm_epi(mocr_engine* e, const GemmParams& p, int epi, int split) {
+    switch (epi) {
+        case EPI_SLAB: launch_gemm_t<T, BM, BN, EPI_SLAB>(e, p, split); break;
+        case EPI_BIAS: launch_gemm_t<T, BM, BN, EPI_BIAS>(e, p, split); break;
+        case EPI_BIAS_GELU: launch_gemm_t<T, BM, BN, EPI_BIAS_GELU>(e, p, split); break;
+        case EPI_BIAS_RESID: launch_gemm_t<T, BM, BN, EPI_BIAS_RESID>(e, p, split); break;
+        case EPI_PATCH: launch_gemm_t<T, BM, BN, EPI_PATCH>(e, p, split); break;
+        case EPI_BIAS_F32: launch_gemm_t<T, BM, BN, EPI_BIAS_F32>(e, p, split); break;
+        default: throw ArgError{"unknown GEMM epilogue", MOCR_ERR_ARG};
+    }
+}
+
+// A [M,K] (lda), W [N,K] (ldw=K), out (ldo).  tile: 128 or 64.  split > 1 only with EPI_SLAB.
+template <typename T>
+void gemm(mocr_engine* e, const char* name, const void* A, int lda, const void* W, const float* bias, void* out, int ldo,
+          const float* resid, int M, int N, int K, int epi, int tile, int split, long long slab_stride = 0,
+          const float* pos = nullptr, int patches = 0) {
+    const int kt = 128 / (int)sizeof(T);
+    if (N % tile || K % (kt * split) || (split > 1 && epi != EPI_SLAB))
+        throw ArgError{std::string("gemm shape not tileable: ") + name, MOCR_ERR_ARG};
+    GemmParams p{};
+    p.A = A; p.W = W; p.bias = bias; p.out = out; p.resid = resid; p.pos = pos;
+    p.M = M; p.N = N; p.lda = lda; p.ldw = K; p.ldo = ldo;
+    p.k_per_split = K / split; p.slab_stride = slab_stride; p.patches = patches;
+    const double out_b = (epi == EPI_BIAS || epi == EPI_BIAS_GELU) ? sizeof(T) : 4.0;
+    const double bytes = ((double)M * K + (double)N * K) * sizeof(T) + (double)M * N * out_b * (epi == EPI_SLAB ? split : 1) +
+                         (epi == EPI_BIAS_RESID ? (double)M * N * 4 : 0);
+    ProfScope ps(e, name, 2.0 * M * N * K, bytes);
+    if (tile == 128) launch_gemm_epi<T, 128, 128>(e, p, epi, split);
+    else if (tile == 64) launch_gemm_epi<T, 64, 64>(e, p, epi, split);
+    else throw ArgError{"gemm tile must be 64 or 128", MOCR_ERR_ARG};
+}
+
+// ---------------------------------------------------------------------------------------- encoder
+template <typename T>
+void layernorm(mocr_engine* e, const float* x, const float* g, const float* b, void* out, int M) {
+    ProfScope ps(e, "layernorm", 0, (double)M * e->D * (4 + sizeof(T)));
+    hipLaunchKernelGGL((layernorm_kernel<T, 768>), dim3((M + 3) / 4), dim3(256), 0, e->stream, x, g, b,
+                       reinterpret_cast<T*>(out), M, e->cfg.ln_eps);
+    HIPCHECK(hipGetLastError());
+}
+
+template <typename T>
+void enc_attention(mocr_engine* e, const void* qkv, void* ctx, int n, int impl) {
+    const int S = e->S, H = e->H;
+    const double flops = 4.0 * n * H * (double)S * S * 64;
+    const double bytes = (double)n * S * e->D * 4 * sizeof(T);
+    if (impl == 1 && sizeof(T) == 2) {
+        ProfScope ps(e, "enc_attn_mfma", flops, bytes);
+        constexpr int lds = ENC_SP * 128 + 64 * ENC_VT_LD * 2;
+        static bool once = false;
+        if (!once) { set_max_lds(enc_attn_mfma_kernel, lds); once = true; }
+        hipLaunchKernelGGL(enc_attn_mfma_kernel, dim3(n * H), dim3(256), lds, e->stream,
+                           reinterpret_cast<const bf16_t*>(qkv), reinterpret_cast<bf16_t*>(ctx), H, 3 * e->D, e->D);
+    } else {
+        ProfScope ps(e, "enc_attn_simple", flops, bytes);
+        constexpr int lds = (200 * 65 + 200 * 64 + 4 * 64 + 4 * 256) * 4;
+        static bool once = false;
+        if (!once) { set_max_lds(enc_attn_simple_kernel<T>, lds); once = true; }
+        hipLaunchKernelGGL((enc_attn_simple_kernel<T>), dim3(n * H), dim3(256), lds, e->stream,
+                           reinterpret_cast<const T*>(qkv), reinterpret_cast<T*>(ctx), S, H, 3 * e->D, e->D, 0.125f);
+    }
+    HIPCHECK(hipGetLastError());
+}
+
+template <typename T>
+void run_encoder(mocr_engine* e, const uint8_t* d_gray, int n) {
+    const int D = e->D, F = e->F, S = e->S, M = n * S, P = e->cfg.patch_size, IMG = e->cfg.image_size;
+    const int NP = e->G * e->G, MPATCH = n * NP;
+    auto& w = e->w;
+    {
+        const long long total = (long long)n * IMG * e->G;
+        ProfScope ps(e, "patchify", 0, (double)n * IMG * IMG * (1 + sizeof(T)));
+        hipLaunchKernelGGL((patchify_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, e->stream, d_gray,
+                           w.lut, reinterpret_cast<T*>(e->Hb), n, IMG, P);
+        HIPCHECK(hipGetLastError());
+    }
+    {
+        ProfScope ps(e, "cls_rows", 0, (double)n * D * 4);
+        hipLaunchKernelGGL(cls_rows_kernel, dim3((n * D + 255) / 256), dim3(256), 0, e->stream, w.cls, w.pos_enc, e->X, n, S, D);
+        HIPCHECK(hipGetLastError());
+    }
+    gemm<T>(e, "gemm_patch_embed", e->Hb, P * P, w.wpe, w.bpe, e->X, D, nullptr, MPATCH, D, P * P, EPI_PATCH, 128, 1, 0,
+            w.pos_enc, NP);
+    const int impl = (e->cfg.flags & MOCR_FLAG_SIMPLE_ATTENTION) ? 0 : 1;
+    for (int l = 0; l < e->cfg.enc_layers; ++l) {
+        const EncLayerW& L = w.enc[l];
+        layernorm<T>(e, e->X, L.ln1g, L.ln1b, e->Xn, M);
+        gemm<T>(e, "gemm_enc_qkv", e->Xn, D, L.wqkv, L.bqkv, e->QKV, 3 * D, nullptr, M, 3 * D, D, EPI_BIAS, 128, 1);
+        enc_attention<T>(e, e->QKV, e->CTX, n, impl);
+        gemm<T>(e, "gemm_enc_oproj", e->CTX, D, L.wo, L.bo, e->X, D, e->X, M, D, D, EPI_BIAS_RESID, 128, 1);
+        layernorm<T>(e, e->X, L.ln2g, L.ln2b, e->Xn, M);
+        gemm<T>(e, "gemm_enc_fc1", e->Xn, D, L.w1, L.b1, e->Hb, F, nullptr, M, F, D, EPI_BIAS_GELU, 128, 1);
+        gemm<T>(e, "gemm_enc_fc2", e->Hb, F, L.w2, L.b2, e->X, D, e->X, M, D, F, EPI_BIAS_RESID, 128, 1);
+    }
+    layernorm<T>(e, e->X, w.lnfg, w.lnfb, e->ENC, M);
+}
+
+// ---------------------------------------------------------------------------------------- decoder
+static int pick_split(int N, int K, int kt, int rows, long long slab_cap_per_row) {
+    // enough blocks to cover the chip (64x64 tiles), bounded by K-tiles and the slab buffer
+    const int tiles = (N / 64) * ((rows + 63) / 64);
+    int split = 1;
+    const int ktiles = K / kt;
+    while (split * 2 <= ktiles && ktiles % (split * 2) == 0 && tiles * split < 384 &&
+           (long long)(split * 2) * N <= slab_cap_per_row)
+        split *= 2;
+    // K = 768 has 12 (bf16) or 24 (fp32) K-tiles: allow the factor 3 as well
+    if (ktiles % (split * 3) == 0 && tiles * split < 256 && (long long)(split * 3) * N <= slab_cap_per_row) split *= 3;
+    return split;
+}
+
+template <typename T>
+int dec_gemm(mocr_engine* e, const char* name, const void* A, int lda, const void* W, int N, int K, int rows) {
+    const int kt = 128 / (int)sizeof(T);
+    const int split = pick_split(N, K, kt, rows, e->slab_cap / e->Bp);
+    gemm<T>(e, name, A, lda, W, nullptr, e->slabs, N, nullptr, rows, N, K, EPI_SLAB, 64, split, (long long)e->Bp * N);
+    return split;
+}
+
+template <typename T>
+void dec_add_ln(mocr_engine* e, int nslab, int N, const float* bias, const float* resid, const float* g, const float* b,
+                float* out_f32, void* out_t, int rows, bool gelu) {
+    ProfScope ps(e, "dec_add_ln", 0, (double)rows * N * 4 * (nslab + 3));
+    if (gelu)
+        hipLaunchKernelGGL((dec_add_ln_kernel<T, 768, true>), dim3((rows + 3) / 4), dim3(256), 0, e->stream, e->slabs, nslab,
+                           (long long)e->Bp * N, bias, resid, g, b, out_f32, reinterpret_cast<T*>(out_t), rows, e->cfg.ln_eps);
+    else
+        hipLaunchKernelGGL((dec_add_ln_kernel<T, 768, false>), dim3((rows + 3) / 4), dim3(256), 0, e->stream, e->slabs, nslab,
+                           (long long)e->Bp * N, bias, resid, g, b, out_f32, reinterpret_cast<T*>(out_t), rows, e->cfg.ln_eps);
+    HIPCHECK(hipGetLastError());
+}
+
+static DecState make_state(mocr_engine* e, int max_len, const int* forced, int forced_T, float* logits_out) {
+    DecState st{};
+    st.ids = e->ids; st.step = e->step; st.finished = e->finished; st.len = e->len; st.n_unfinished = e->n_unf;
+    st.forced = forced; st.forced_T = forced_T; st.logits_out = logits_out;
+    st.ids_ld = e->cfg.max_len; st.max_len = max_len;
+    st.start_id = e->cfg.start_id; st.eos_id = e->cfg.eos_id; st.pad_id = e->cfg.pad_id;
+    return st;
+}
+
+template <typename T, bool FIRST>
+void dec_token(mocr_engine* e, const DecState& st, int nslab, int n) {
+    auto& w = e->w;
+    ProfScope ps(e, FIRST ? "dec_token_first" : "dec_token", 0, FIRST ? 0.0 : (double)n * e->V * 4 * nslab);
+    hipLaunchKernelGGL((dec_token_kernel<T, 768, FIRST>), dim3(n), dim3(256), 0, e->stream, e->slabs, nslab,
+                       (long long)e->Bp * e->V, w.bv, e->V, st, w.word, w.type0, w.posd, w.embg, w.embb, e->x_f32,
+                       reinterpret_cast<T*>(e->x_t), e->cfg.ln_eps);
+    HIPCHECK(hipGetLastError());
+}
+
+template <typename T, bool SELF>
+void dec_attn(mocr_engine* e, int layer, int nslab, int n, const float* bias, int approx_len) {
+    const int D = e->D, H = e->H;
+    DecAttnParams p{};
+    p.slabs = e->slabs; p.nslab = nslab;
+    p.ldq = SELF ? 3 * D : D;
+    p.slab_stride = (long long)e->Bp * p.ldq;
+    p.bias = bias;
+    if (SELF) {
+        const size_t per_layer = (size_t)e->Bp * H * e->cfg.max_len * 64;
+        p.kbase = reinterpret_cast<char*>(e->kcache) + (size_t)layer * per_layer * sizeof(T);
+        p.vbase = reinterpret_cast<char*>(e->vcache) + (size_t)layer * per_layer * sizeof(T);
+        p.kv_batch_stride = (long long)H * e->cfg.max_len * 64;
+        p.kv_head_stride = (long long)e->cfg.max_len * 64;
+        p.kv_row_stride = 64;
+        p.step = e->step;
+    } else {
+        p.kbase = reinterpret_cast<char*>(e->CKV) + (size_t)(layer * 2 * D) * sizeof(T);
+        p.vbase = reinterpret_cast<char*>(e->CKV) + (size_t)(layer * 2 * D + D) * sizeof(T);
+        p.kv_batch_stride = (long long)e->S * e->NCKV;
+        p.kv_head_stride = 64;
+        p.kv_row_stride = e->NCKV;
+        p.cross_len = e->S;
+    }
+    p.ctx = e->ctx_t; p.H = H; p.scale = 0.125f;
+    ProfScope ps(e, SELF ? "dec_attn_self" : "dec_attn_cross", 4.0 * n * H * approx_len * 64,
+                 2.0 * n * H * approx_len * 64 * sizeof(T));
+    hipLaunchKernelGGL((dec_attn_kernel<T, SELF>), dim3(n * (H / 4)), dim3(256), 0, e->stream, p);
+    HIPCHECK(hipGetLastError());
+}
+
+// One greedy step for n rows; `t` is only used for the profiler's byte estimate.
+template <typename T>
+void decode_step(mocr_engine* e, const DecState& st, int n, int t) {
+    const int D = e->D, F = e->F;
+    auto& w = e->w;
+    const void* xin = e->x_t;
+    const float* xres = e->x_f32;
+    for (int l = 0; l < e->cfg.dec_layers; ++l) {
+        const DecLayerW& L = w.dec[l];
+        int ns = dec_gemm<T>(e, "gemm_dec_qkv", xin, D, L.wqkv, 3 * D, D, n);
+        dec_attn<T, true>(e, l, ns, n, L.bqkv, t + 1);
+        ns = dec_gemm<T>(e, "gemm_dec_proj", e->ctx_t, D, L.wo, D, D, n);
+        dec_add_ln<T>(e, ns, D, L.bo, xres, L.ln1g, L.ln1b, e->a_f32, e->a_t, n, false);
+        ns = dec_gemm<T>(e, "gemm_dec_proj", e->a_t, D, L.wqc, D, D, n);
+        dec_attn<T, false>(e, l, ns, n, L.bqc, e->S);
+        ns = dec_gemm<T>(e, "gemm_dec_proj", e->ctx_t, D, L.woc, D, D, n);
+        dec_add_ln<T>(e, ns, D, L.boc, e->a_f32, L.ln2g, L.ln2b, e->c_f32, e->c_t, n, false);
+        ns = dec_gemm<T>(e, "gemm_dec_fc1", e->c_t, D, L.w1, F, D, n);
+        {
+            ProfScope ps(e, "dec_bias_gelu", 0, (double)n * F * (4.0 * ns + sizeof(T)));
+            hipLaunchKernelGGL((dec_bias_gelu_kernel<T>), dim3((n * F / 4 + 255) / 256), dim3(256), 0, e->stream, e->slabs, ns,
+                               (long long)e->Bp * F, L.b1, reinterpret_cast<T*>(e->h_t), n, F);
+            HIPCHECK(hipGetLastError());
+        }
+        ns = dec_gemm<T>(e, "gemm_dec_fc2", e->h_t, F, L.w2, D, F, n);
+        dec_add_ln<T>(e, ns, D, L.b2, e->c_f32, L.ln3g, L.ln3b, e->x_f32, e->x_t, n, false);
+        xin = e->x_t; xres = e->x_f32;
+    }
+    int ns = dec_gemm<T>(e, "gemm_dec_proj", e->x_t, D, w.wt, D, D, n);
+    dec_add_ln<T>(e, ns, D, w.bt, nullptr, w.lntg, w.lntb, nullptr, e->z_t, n, true);
+    ns = dec_gemm<T>(e, "gemm_dec_vocab", e->z_t, D, w.wv, e->V, D, n);
+    dec_token<T, false>(e, st, ns, n);
+}
+
+template <typename T>
+void run_cross_kv(mocr_engine* e, int n) {
+    gemm<T>(e, "gemm_cross_kv", e->ENC, e->D, e->w.wckv, e->w.bckv, e->CKV, e->NCKV, nullptr, n * e->S, e->NCKV, e->D,
+            EPI_BIAS, 128, 1);
+}
+
+// Greedy loop.  Returns the number of steps launched.
+template <typename T>
+int run_decode(mocr_engine* e, int n, int max_len, const int* forced, int forced_T, float* logits_out, bool allow_sync) {
+    DecState st = make_state(e, max_len, forced, forced_T, logits_out);
+    dec_token<T, true>(e, st, 0, n);
+    const int steps = forced ? forced_T : max_len - 1;
+    const bool early = allow_sync && !forced && !(e->cfg.flags & MOCR_FLAG_NO_EARLY_EXIT);
+    int t = 0;
+    for (; t < steps; ++t) {
+        decode_step<T>(e, st, n, t);
+        if (early && (t % 16) == 15 && t + 1 < steps) {
+            HIPCHECK(hipMemcpyAsync(e->h_pinned, e->n_unf, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+            HIPCHECK(hipStreamSynchronize(e->stream));
+            if (*e->h_pinned <= 0) { ++t; break; }
+        }
+    }
+    return t;
+}
+
+template <typename T>
+void recognize_batch(mocr_engine* e, const uint8_t* d_gray, int n, int max_len, bool allow_sync) {
+    run_encoder<T>(e, d_gray, n);
+    run_cross_kv<T>(e, n);
+    // ids rows must read pad_id beyond what the loop writes
+    HIPCHECK(hipMemsetAsync(e->ids, 0, (size_t)n * e->cfg.max_len * sizeof(int), e->stream));
+    if (e->cfg.pad_id != 0) throw ArgError{"pad_id != 0 is not supported", MOCR_ERR_UNSUPPORTED};
+    run_decode<T>(e, n, max_len, nullptr, 0, nullptr, allow_sync);
+}
+
+// ---------------------------------------------------------------------------------------- weights
+struct Uploader {
+    mocr_engine* e;
+    const std::vector<float>& get(const std::string& name, std::initializer_list<int64_t> shape) {
+        auto it = e->host_w.find(name);
+        if (it == e->host_w.end()) throw ArgError{"missing tensor " + name, MOCR_ERR_STATE};
+        const auto& shp = e->host_shape[name];
+        std::vector<int64_t> want(shape);
+        if (shp != want) throw ArgError{"bad shape for tensor " + name, MOCR_ERR_ARG};
+        return it->second;
+    }
+    float* f32(const std::vector<float>& v) {
+        float* d = e->dalloc<float>(v.size());
+        HIPCHECK(hipMemcpy(d, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+        return d;
+    }
+    void* mat(const std::vector<float>& v) {  // GEMM operand in the engine dtype
+        if (e->cfg.dtype == MOCR_F32) return f32(v);
+        std::vector<uint16_t> h(v.size());
+        for (size_t i = 0; i < v.size(); ++i) h[i] = host_f2bf(v[i]);
+        uint16_t* d = e->dalloc<uint16_t>(h.size());
+        HIPCHECK(hipMemcpy(d, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+        return d;
+    }
+};
+
+static std::vector<float> concat(std::initializer_list<const std::vector<float>*> parts) {
+    std::vector<float> out;
+    for (auto* p : parts) out.insert(out.end(), p->begin(), p->end());
+    return out;
+}
+
+void commit_weights(mocr_engine* e) {
+    const auto& c = e->cfg;
+    const int64_t D = c.hidden, F = c.ffn, V = c.vocab, P = c.patch_size, S = e->S;
+    Uploader up{e};
+    auto& w = e->w;
+    // pixel LUT, exactly the HF image processor's arithmetic (float64 rescale, float32 normalise)
+    {
+        std::vector<float> lut(256);
+        for (int u = 0; u < 256; ++u) {
+            const float x = (float)((double)u * (1.0 / 255.0));
+            lut[u] = (x - 0.5f) / 0.5f;
+        }
+        w.lut = up.f32(lut);
+    }
+    // patch embedding: the three input channels are identical, so sum the kernel over channels
+    {
+        const auto& pw = up.get("encoder.embeddings.patch_embeddings.projection.weight", {D, 3, P, P});
+        std::vector<float> ws((size_t)D * P * P);
+        for (int64_t o = 0; o < D; ++o)
+            for (int64_t k = 0; k < P * P; ++k) {
+                double s = 0;
+                for (int ch = 0; ch < 3; ++ch) s += pw[(o * 3 + ch) * P * P + k];
+                ws[o * P * P + k] = (float)s;
+            }
+        w.wpe = up.mat(ws);
+        w.bpe = up.f32(up.get("encoder.embeddings.patch_embeddings.projection.bias", {D}));
+        w.cls = up.f32(up.get("encoder.embeddings.cls_token", {1, 1, D}));
+        w.pos_enc = up.f32(up.get("encoder.embeddings.position_embeddings", {1, S, D}));
+    }
+    w.enc.resize(c.enc_layers);
+    for (int l = 0; l < c.enc_layers; ++l) {
+        const std::string p = "encoder.layers." + std::to_string(l) + ".";
+        EncLayerW& L = w.enc[l];
+        L.wqkv = up.mat(concat({&up.get(p + "attention.q_proj.weight", {D, D}), &up.get(p + "attention.k_proj.weight", {D, D}),
+                                &up.get(p + "attention.v_proj.weight", {D, D})}));
+        L.bqkv = up.f32(concat({&up.get(p + "attention.q_proj.bias", {D}), &up.get(p + "attention.k_proj.bias", {D}),
+                                &up.get(p + "attention.v_proj.bias", {D})}));
+        L.wo = up.mat(up.get(p + "attention.o_proj.weight", {D, D}));
+        L.bo = up.f32(up.get(p + "attention.o_proj.bias", {D}));
+        L.ln1g = up.f32(up.get(p + "layernorm_before.weight", {D}));
+        L.ln1b = up.f32(up.get(p + "layernorm_before.bias", {D}));
+        L.ln2g = up.f32(up.get(p + "layernorm_after.weight", {D}));
+        L.ln2b = up.f32(up.get(p + "layernorm_after.bias", {D}));
+        L.w1 = up.mat(up.get(p + "mlp.fc1.weight", {F, D}));
+        L.b1 = up.f32(up.get(p + "mlp.fc1.bias", {F}));
+        L.w2 = up.mat(up.get(p + "mlp.fc2.weight", {D, F}));
+        L.b2 = up.f32(up.get(p + "mlp.fc2.bias", {D}));
+    }
+    w.lnfg = up.f32(up.get("encoder.layernorm.weight", {D}));
+    w.lnfb = up.f32(up.get("encoder.layernorm.bias", {D}));
+    const std::string d = "decoder.bert.";
+    w.word = up.f32(up.get(d + "embeddings.word_embeddings.weight", {V, D}));
+    w.posd = up.f32(up.get(d + "embeddings.position_embeddings.weight", {(int64_t)c.max_pos, D}));
+    {
+        const auto& tt = e->host_w.at(d + "embeddings.token_type_embeddings.weight");
+        std::vector<float> t0(tt.begin(), tt.begin() + D);
+        w.type0 = up.f32(t0);
+    }
+    w.embg = up.f32(up.get(d + "embeddings.LayerNorm.weight", {D}));
+    w.embb = up.f32(up.get(d + "embeddings.LayerNorm.bias", {D}));
+    w.dec.resize(c.dec_layers);
+    std::vector<float> ckv_w, ckv_b;
+    for (int l = 0; l < c.dec_layers; ++l) {
+        const std::string p = d + "encoder.layer." + std::to_string(l) + ".";
+        DecLayerW& L = w.dec[l];
+        const std::string a = p + "attention.", x = p + "crossattention.";
+        L.wqkv = up.mat(concat({&up.get(a + "self.query.weight", {D, D}), &up.get(a + "self.key.weight", {D, D}),
+                                &up.get(a + "self.value.weight", {D, D})}));
+        L.bqkv = up.f32(concat({&up.get(a + "self.query.bias", {D}), &up.get(a + "self.key.bias", {D}),
+                                &up.get(a + "self.value.bias", {D})}));
+        L.wo = up.mat(up.get(a + "output.dense.weight", {D, D}));
+        L.bo = up.f32(up.get(a + "output.dense.bias", {D}));
+        L.ln1g = up.f32(up.get(a + "output.LayerNorm.weight", {D}));
+        L.ln1b = up.f32(up.get(a + "output.LayerNorm.bias", {D}));
+        L.wqc = up.mat(up.get(x + "self.query.weight", {D, D}));
+        L.bqc = up.f32(up.get(x + "self.query.bias", {D}));
+        for (const char* kv : {"self.key.", "self.value."}) {
+            const auto& ww = up.get(x + kv + "weight", {D, D});
+            const auto& bb = up.get(x + kv + "bias", {D});
+            ckv_w.insert(ckv_w.end(), ww.begin(), ww.end());
+            ckv_b.insert(ckv_b.end(), bb.begin(), bb.end());
+        }
+        L.woc = up.mat(up.get(x + "output.dense.weight", {D, D}));
+        L.boc = up.f32(up.get(x + "output.dense.bias", {D}));
+        L.ln2g = up.f32(up.get(x + "output.LayerNorm.weight", {D}));
+        L.ln2b = up.f32(up.get(x + "output.LayerNorm.bias", {D}));
+        L.w1 = up.mat(up.get(p + "intermediate.dense.weight", {F, D}));
+        L.b1 = up.f32(up.get(p + "intermediate.dense.bias", {F}));
+        L.w2 = up.mat(up.get(p + "output.dense.weight", {D, F}));
+        L.b2 = up.f32(up.get(p + "output.dense.bias", {D}));
+        L.ln3g = up.f32(up.get(p + "output.LayerNorm.weight", {D}));
+        L.ln3b = up.f32(up.get(p + "output.LayerNorm.bias", {D}));
+    }
+    w.wckv = up.mat(ckv_w);
+    w.bckv = up.f32(ckv_b);
+    const std::string cl = "decoder.cls.predictions.";
+    w.wt = up.mat(up.get(cl + "transform.dense.weight", {D, D}));
+    w.bt = up.f32(up.get(cl + "transform.dense.bias", {D}));
+    w.lntg = up.f32(up.get(cl + "transform.LayerNorm.weight", {D}));
+    w.lntb = up.f32(up.get(cl + "transform.LayerNorm.bias", {D}));
+    w.wv = up.mat(up.get(cl + "decoder.weight", {V, D}));
+    w.bv = up.f32(up.get(cl + "decoder.bias", {V}));
+    e->host_w.clear();
+    e->host_shape.clear();
+    e->committed = true;
+}
+
+void allocate_workspace(mocr_engine* e) {
+    const auto& c = e->cfg;
+    e->S = (c.image_size / c.patch_size) * (c.image_size / c.patch_size) + 1;
+    e->G = c.image_size / c.patch_size;
+    e->D = c.hidden; e->H = c.heads; e->F = c.ffn; e->V = c.vocab;
+    e->esz = c.dtype == MOCR_BF16 ? 2 : 4;
+    e->Bp = round_up(c.max_batch, 128);
+    e->Mp = round_up(c.max_batch * e->S, 128) + 128;
+    e->NCKV = c.dec_layers * 2 * c.hidden;
+    const size_t Mp = e->Mp, D = e->D, Bp = e->Bp, esz = e->esz;
+    e->d_in = e->dalloc<uint8_t>((size_t)c.max_batch * c.image_size * c.image_size);
+    e->d_rgb = e->dalloc<uint8_t>((size_t)c.max_batch * c.image_size * c.image_size * 3);
+    e->X = e->dalloc<float>(Mp * D);
+    e->Xn = e->dalloc<char>(Mp * D * esz);
+    e->QKV = e->dalloc<char>(Mp * 3 * D * esz);
+    e->CTX = e->dalloc<char>(Mp * D * esz);
+    e->Hb = e->dalloc<char>(Mp * (size_t)e->F * esz);
+    e->ENC = e->dalloc<char>(Mp * D * esz);
+    e->CKV = e->dalloc<char>(Mp * (size_t)e->NCKV * esz);
+    const size_t cache = (size_t)c.dec_layers * Bp * e->H * c.max_len * 64 * esz;
+    e->kcache = e->dalloc<char>(cache);
+    e->vcache = e->dalloc<char>(cache);
+    e->slab_cap = (long long)Bp * 12288;
+    e->slabs = e->dalloc<float>((size_t)e->slab_cap);
+    e->x_f32 = e->dalloc<float>(Bp * D); e->a_f32 = e->dalloc<float>(Bp * D); e->c_f32 = e->dalloc<float>(Bp * D);
+    e->x_t = e->dalloc<char>(Bp * D * esz); e->a_t = e->dalloc<char>(Bp * D * esz); e->c_t = e->dalloc<char>(Bp * D * esz);
+    e->ctx_t = e->dalloc<char>(Bp * D * esz); e->z_t = e->dalloc<char>(Bp * D * esz);
+    e->h_t = e->dalloc<char>(Bp * (size_t)e->F * esz);
+    e->ids = e->dalloc<int>(Bp * (size_t)c.max_len);
+    e->step = e->dalloc<int>(Bp); e->finished = e->dalloc<int>(Bp); e->len = e->dalloc<int>(Bp); e->n_unf = e->dalloc<int>(4);
+    HIPCHECK(hipHostMalloc(reinterpret_cast<void**>(&e->h_pinned), 64, hipHostMallocDefault));
+}
+
+template <typename F> int guarded(mocr_engine* e, F&& f) {
+    if (!e) return MOCR_ERR_ARG;
+    try {
+        f();
+        return MOCR_OK;
+    } catch (const HipError& h) {
+        char buf[512];
+        snprintf(buf, sizeof(buf), "HIP error %d (%s) at engine.hip:%d: %s", (int)h.code, hipGetErrorString(h.code), h.line, h.what);
+        e->err = buf;
+        return MOCR_ERR_HIP;
+    } catch (const ArgError& a) {
+        e->err = a.msg;
+        return a.code;
+    } catch (const std::bad_alloc&) {
+        e->err = "host allocation failed";
+        return MOCR_ERR_NOMEM;
+    } catch (const std::exception& x) {
+        e->err = x.what();
+        return MOCR_ERR_STATE;
+    }
+}
+
+void require_ready(mocr_engine* e, int n, bool bounded = true) {
+    if (!e->committed) throw ArgError{"weights not committed (mocr_commit_weights)", MOCR_ERR_STATE};
+    if (n <= 0) throw ArgError{"n must be positive", MOCR_ERR_ARG};
+    if (bounded && n > e->cfg.max_batch) throw ArgError{"n exceeds max_batch", MOCR_ERR_ARG};
+}
+
+// run fn with T = storage type of the engine: fn(bf16_t{}) or fn(float{})
+template <typename Fn> void dispatch(mocr_engine* e, Fn&& fn) {
+    if (e->cfg.dtype == MOCR_BF16) fn(bf16_t{}); else fn(float{});
+}
+
+}  // namespace
+
+// ============================================================================================ C ABI
+extern "C" {
+
+int mocr_abi_version(void) { return MOCR_ABI_VERSION; }
+
+int mocr_create(const mocr_config* cfg, mocr_engine** out) {
+    if (!cfg || !out || cfg->struct_size != (int32_t)sizeof(mocr_config)) return MOCR_ERR_ARG;
+    if (cfg->hidden != 768 || cfg->heads != 12 || cfg->image_size != 224 || cfg->patch_size != 16 || cfg->ffn % 128 ||
+        cfg->vocab % 1024 || cfg->max_len < 2 || cfg->max_len > 320 || cfg->max_len > cfg->max_pos || cfg->max_batch < 1 ||
+        (cfg->dtype != MOCR_F32 && cfg->dtype != MOCR_BF16) || cfg->enc_layers < 1 || cfg->dec_layers < 1)
+        return MOCR_ERR_UNSUPPORTED;
+    mocr_engine* e = new (std::nothrow) mocr_engine();
+    if (!e) return MOCR_ERR_NOMEM;
+    e->cfg = *cfg;
+    int rc = guarded(e, [&] {
+        int ndev = 0;
+        HIPCHECK(hipGetDeviceCount(&ndev));
+        if (ndev <= 0) throw ArgError{"no HIP device visible: the Manga-OCR engine needs a GPU", MOCR_ERR_HIP};
+        HIPCHECK(hipSetDevice(cfg->device));
+        HIPCHECK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+        allocate_workspace(e);
+    });
+    if (rc != MOCR_OK) {
+        fprintf(stderr, "mocr_create failed: %s\n", e->err.c_str());
+        mocr_destroy(e);
+        return rc;
+    }
+    *out = e;
+    return MOCR_OK;
+}
+
+void mocr_destroy(mocr_engine* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->cfg.device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (auto& r : e->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
+    for (void* p : e->allocs) (void)hipFree(p);
+    if (e->h_pinned) (void)hipHostFree(e->h_pinned);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+const char* mocr_last_error(const mocr_engine* e) { return e ? e->err.c_str() : "null engine"; }
+
+int mocr_set_tensor(mocr_engine* e, const char* name, const float* data, const int64_t* shape, int32_t ndim) {
+    return guarded(e, [&] {
+        if (!name || !data || !shape || ndim < 1 || ndim > 4) throw ArgError{"mocr_set_tensor: bad argument", MOCR_ERR_ARG};
+        if (e->committed) throw ArgError{"weights already committed", MOCR_ERR_STATE};
+        std::lock_guard<std::mutex> lk(e->mu);
+        int64_t count = 1;
+        for (int i = 0; i < ndim; ++i) count *= shape[i];
+        e->host_w[name].assign(data, data + count);
+        e->host_shape[name].assign(shape, shape + ndim);
+    });
+}
+
+int mocr_commit_weights(mocr_engine* e) {
+    return guarded(e, [&] {
+        std::lock_guard<std::mutex> lk(e->mu);
+        if (e->committed) throw ArgError{"weights already committed", MOCR_ERR_STATE};
+        HIPCHECK(hipSetDevice(e->cfg.device));
+        commit_weights(e);
+    });
+}
+
+void* mocr_stream(mocr_engine* e) { return e ? (void*)e->stream : nullptr; }
+
+int mocr_synchronize(mocr_engine* e) {
+    return guarded(e, [&] { HIPCHECK(hipSetDevice(e->cfg.device)); HIPCHECK(hipStreamSynchronize(e->stream)); });
+}
+
+int mocr_recognize_device(mocr_engine* e, const void* d_gray, int32_t n, void* d_out_ids, void* d_out_len) {
+    return guarded(e, [&] {
+        std::lock_guard<std::mutex> lk(e->mu);
+        require_ready(e, n);
+        if (!d_gray || !d_out_ids || !d_out_len) throw ArgError{"null device pointer", MOCR_ERR_ARG};
+        HIPCHECK(hipSetDevice(e->cfg.device));
+        const uint8_t* g = reinterpret_cast<const uint8_t*>(d_gray);
+        dispatch(e, [&](auto tag) { recognize_batch<decltype(tag)>(e, g, n, e->cfg.max_len, false); });
+        HIPCHECK(hipMemcpyAsync(d_out_ids, e->ids, (size_t)n * e->cfg.max_len * sizeof(int), hipMemcpyDeviceToDevice, e->stream));
+        HIPCHECK(hipMemcpyAsync(d_out_len, e->len, (size_t)n * sizeof(int), hipMemcpyDeviceToDevice, e->stream));
+    });
+}
+
+static void recognize_host_chunks(mocr_engine* e, const uint8_t* images, int n, int h, int w, int64_t row_stride,
+                                  int64_t image_stride, int channels, int max_len, int32_t* out_ids, int32_t* out_len) {
+    const int IMG = e->cfg.image_size;
+    if (h != IMG || w != IMG)
+        throw ArgError{"crops must be image_size x image_size (resize with PIL BILINEAR on the caller side)", MOCR_ERR_UNSUPPORTED};
+    if (channels != 1 && channels != 3) throw ArgError{"channels must be 1 (L) or 3 (RGB)", MOCR_ERR_ARG};
+    if (!images || !out_ids || !out_len) throw ArgError{"null pointer", MOCR_ERR_ARG};
+    if (max_len < 2 || max_len > e->cfg.max_len) throw ArgError{"bad max_len override", MOCR_ERR_ARG};
+    const size_t rowb = (size_t)IMG * channels;
+    for (int base = 0; base < n; base += e->cfg.max_batch) {
+        const int nb = std::min(e->cfg.max_batch, n - base);
+        uint8_t* dst = channels == 1 ? e->d_in : e->d_rgb;
+        for (int i = 0; i < nb; ++i)
+            HIPCHECK(hipMemcpy2DAsync(dst + (size_t)i * IMG * rowb, rowb, images + (size_t)(base + i) * image_stride, row_stride,
+                                      rowb, IMG, hipMemcpyHostToDevice, e->stream));
+        if (channels == 3) {
+            const long long npix = (long long)nb * IMG * IMG;
+            hipLaunchKernelGGL(rgb_to_l_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, e->stream, e->d_rgb, e->d_in, npix);
+            HIPCHECK(hipGetLastError());
+        }
+        dispatch(e, [&](auto tag) { recognize_batch<decltype(tag)>(e, e->d_in, nb, max_len, true); });
+        HIPCHECK(hipMemcpyAsync(out_ids + (size_t)base * e->cfg.max_len, e->ids, (size_t)nb * e->cfg.max_len * sizeof(int),
+                                hipMemcpyDeviceToHost, e->stream));
+        HIPCHECK(hipMemcpyAsync(out_len + base, e->len, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+        HIPCHECK(hipStreamSynchronize(e->stream));
+    }
+}
+
+int mocr_recognize(mocr_engine* e, const uint8_t* images, int32_t n, int32_t h, int32_t w, int64_t row_stride,
+                   int64_t image_stride, int32_t channels, int32_t* out_ids, int32_t* out_len) {
+    return guarded(e, [&] {
+        std::lock_guard<std::mutex> lk(e->mu);
+        require_ready(e, n, false);
+        HIPCHECK(hipSetDevice(e->cfg.device));
+        recognize_host_chunks(e, images, n, h, w, row_stride, image_stride, channels, e->cfg.max_len, out_ids, out_len);
+    });
+}
+
+int mocr_recognize_gray_host(mocr_engine* e, const uint8_t* gray, int32_t n, int32_t max_len_override, int32_t* out_ids,
+                             int32_t* out_len) {
+    return guarded(e, [&] {
+        std::lock_guard<std::mutex> lk(e->mu);
+        require_ready(e, n, false);
+        HIPCHECK(hipSetDevice(e->cfg.device));
+        const int IMG = e->cfg.image_size;
+        recognize_host_chunks(e, gray, n, IMG, IMG, IMG, (int64_t)IMG * IMG, 1, max_len_override, out_ids, out_len);
+    });
+}
+
+int mocr_encode(mocr_engine* e, const void* d_gray, int32_t n, float* h_out) {
+    return guarded(e, [&] {
+        std::lock_guard<std::mutex> lk(e->mu);
+        require_ready(e, n);
+        if (!d_gray || !h_out) throw ArgError{"null pointer", MOCR_ERR_ARG};
+        HIPCHECK(hipSetDevice(e->cfg.device));
+        const uint8_t* g = reinterpret_cast<const uint8_t*>(d_gray);
+        dispatch(e, [&](auto tag) { run_encoder<decltype(tag)>(e, g, n); });
+        const size_t count = (size_t)n * e->S * e->D;
+        if (e->cfg.dtype == MOCR_F32) {
+            HIPCHECK(hipMemcpyAsync(h_out, e->ENC, count * 4, hipMemcpyDeviceToHost, e->stream));
+            HIPCHECK(hipStreamSynchronize(e->stream));
+        } else {
+            std::vector<uint16_t> tmp(count);
+            HIPCHECK(hipMemcpyAsync(tmp.data(), e->ENC, count * 2, hipMemcpyDeviceToHost, e->stream));
+            HIPCHECK(hipStreamSynchronize(e->stream));
+            for (size_t i = 0; i < count; ++i) {
+                const uint32_t u = (uint32_t)tmp[i] << 16;
+                memcpy(&h_out[i], &u, 4);
+            }
+        }
+    });
+}
+
+int mocr_decode_logits(mocr_engine* e, const void* d_gray, int32_t n, const int32_t* forced_ids, int32_t T, float* h_logits) {
+    return guarded(e, [&] {
+        std::lock_guard<std::mutex> lk(e->mu);
+        require_ready(e, n);
+        if (!d_gray || !forced_ids || !h_logits || T < 1 || T >= e->cfg.max_len) throw ArgError{"bad argument", MOCR_ERR_ARG};
+        HIPCHECK(hipSetDevice(e->cfg.device));
+        const size_t fcount = (size_t)n * T, lcount = (size_t)n * T * e->V;
+        if (fcount > e->forced_cap) { e->forced = e->dalloc<int>(fcount); e->forced_cap = fcount; }
+        if (lcount > e->logits_cap) { e->logits_dbg = e->dalloc<float>(lcount); e->logits_cap = lcount; }
+        HIPCHECK(hipMemcpyAsync(e->forced, forced_ids, fcount * sizeof(int), hipMemcpyHostToDevice, e->stream));
+        const uint8_t* g = reinterpret_cast<const uint8_t*>(d_gray);
+        if (e->cfg.dtype == MOCR_BF16) {
+            run_encoder<bf16_t>(e, g, n); run_cross_kv<bf16_t>(e, n);
+            run_decode<bf16_t>(e, n, e->cfg.max_len, e->forced, T, e->logits_dbg, false);
+        } else {
+            run_encoder<float>(e, g, n); run_cross_kv<float>(e, n);
+            run_decode<float>(e, n, e->cfg.max_len, e->forced, T, e->logits_dbg, false);
+        }
+        HIPCHECK(hipMemcpyAsync(h_logits, e->logits_dbg, lcount * 4, hipMemcpyDeviceToHost, e->stream));
+        HIPCHECK(hipStreamSynchronize(e->stream));
+    });
+}
+
+int mocr_op_gemm(mocr_engine* e, const void* dA, const void* dW, const float* d_bias, void* d_out, const float* d_resid,
+                 int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t tile, int32_t split_k) {
+    return guarded(e, [&] {
+        std::lock_guard<std::mutex> lk(e->mu);
+        HIPCHECK(hipSetDevice(e->cfg.device));
+        if (epilogue == EPI_PATCH) throw ArgError{"EPI_PATCH is not exposed through mocr_op_gemm", MOCR_ERR_ARG};
+        const long long slab = (long long)M * N;
+        if (e->cfg.dtype == MOCR_BF16)
+            gemm<bf16_t>(e, "op_gemm", dA, K, dW, d_bias, d_out, N, d_resid, M, N, K, epilogue, tile, split_k, slab);
+        else
+            gemm<float>(e, "op_gemm", dA, K, dW, d_bias, d_out, N, d_resid, M, N, K, epilogue, tile, split_k, slab);
+        HIPCHECK(hipStreamSynchronize(e->stream));
+    });
+}
+
+int mocr_op_layernorm(mocr_engine* e, const float* d_x, const float* d_gamma, const float* d_beta, void* d_out, int32_t M) {
+    return guarded(e, [&] {
+        std::lock_guard<std::mutex> lk(e->mu);
+        HIPCHECK(hipSetDevice(e->cfg.device));
+        dispatch(e, [&](auto tag) { layernorm<decltype(tag)>(e, d_x, d_gamma, d_beta, d_out, M); });
+        HIPCHECK(hipStreamSynchronize(e->stream));
+    });
+}
+
+int mocr_op_enc_attention(mocr_engine* e, const void* d_qkv, void* d_ctx, int32_t n, int32_t impl) {
+    return guarded(e, [&] {
+        std::lock_guard<std::mutex> lk(e->mu);
+        HIPCHECK(hipSetDevice(e->cfg.device));
+        dispatch(e, [&](auto tag) { enc_attention<decltype(tag)>(e, d_qkv, d_ctx, n, impl); });
+        HIPCHECK(hipStreamSynchronize(e->stream));
+    });
+}
+
+int mocr_profile_enable(mocr_engine* e, int32_t on) {
+    return guarded(e, [&] {
+        std::lock_guard<std::mutex> lk(e->mu);
+        HIPCHECK(hipSetDevice(e->cfg.device));
+        e->prof_collect();
+        e->prof_on = on != 0;
+    });
+}
+
+int mocr_profile_reset(mocr_engine* e) {
+    return guarded(e, [&] {
+        std::lock_guard<std::mutex> lk(e->mu);
+        HIPCHECK(hipSetDevice(e->cfg.device));
+        e->prof_collect();
+        for (auto& s : e->stats) { s.launches = 0; s.total_ms = 0; s.flops = 0; s.bytes = 0; }
+    });
+}
+
+int mocr_profile_get(mocr_engine* e, mocr_kernel_stat* out, int32_t cap, int32_t* n_out) {
+    return guarded(e, [&] {
+        std::lock_guard<std::mutex> lk(e->mu);
+        if (!out || !n_out || cap < 0) throw ArgError{"bad argument", MOCR_ERR_ARG};
+        HIPCHECK(hipSetDevice(e->cfg.device));
+        e->prof_collect();
+        int k = 0;
+        for (auto& s : e->stats)
+            if (s.launches > 0 && k < cap) out[k++] = s;
+        *n_out = k;
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,352 @@
+// Attention kernels.
+//   enc_attn_simple_kernel<T> : encoder self-attention on the VALU, fp32 math (parity mode, and the
+//                               on-device cross-check of the MFMA kernel)
+//   enc_attn_mfma_kernel      : encoder self-attention on the matrix cores (bf16), whole K/V of one
+//                               head resident in LDS, softmax in registers
+//   dec_attn_kernel<T,SELF>   : single-query attention of the decode step over the self cache
+//                               (<= 300 keys, appends the new K/V) or the cross K/V (197 keys).
+//                               HBM-bound: streams each key/value row exactly once, 1 KiB per
+//                               wave-instruction.
+// Encoder sequence = 197 tokens, 12 heads x 64 (TF/models/vit/modeling_vit.py:164-238); no mask.
+#pragma once
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// Encoder attention, VALU.  One block per (image, head); K as fp32 [S][65] and V as fp32 [S][64]
+// in LDS.  Each wave owns every 4th query row: lane j scores keys j, j+64, ...; lane d accumulates
+// output dim d.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void enc_attn_simple_kernel(const T* __restrict__ qkv, T* __restrict__ ctx,
+                                                              int S, int H, int ld_qkv, int ld_ctx, float scale) {
+    constexpr int DH = 64, KP = 65, SMAX = 200;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sK = reinterpret_cast<float*>(smem);                 // [S][65]
+    float* sV = sK + SMAX * KP;                                 // [S][64]
+    float* sQ = sV + SMAX * DH;                                 // [4][64]
+    float* sP = sQ + 4 * DH;                                    // [4][256]
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const T* base = qkv + (size_t)b * S * ld_qkv + h * DH;
+    const int D = H * DH;
+    for (int i = tid; i < S * (DH / 4); i += 256) {
+        const int s = i / (DH / 4), c = (i % (DH / 4)) * 4;
+        float k4[4], v4[4];
+        elem<T>::ld4(base + (size_t)s * ld_qkv + D + c, k4);
+        elem<T>::ld4(base + (size_t)s * ld_qkv + 2 * D + c, v4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sK[s * KP + c + e] = k4[e]; sV[s * DH + c + e] = v4[e]; }
+    }
+    __syncthreads();
+    float* q = sQ + wave * DH;
+    float* pr = sP + wave * 256;
+    for (int qi = wave; qi < S; qi += 4) {
+        q[lane] = elem<T>::ld(base + (size_t)qi * ld_qkv + lane);
+        __builtin_amdgcn_wave_barrier();
+        float sc[4];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int key = lane + 64 * kk;
+            float a = 0.f;
+            if (key < S) {
+                const float* kr = sK + key * KP;
+#pragma unroll 16
+                for (int d = 0; d < DH; ++d) a += q[d] * kr[d];
+                a *= scale;
+                mx = fmaxf(mx, a);
+            }
+            sc[kk] = a;
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int key = lane + 64 * kk;
+            const float e = key < S ? expf(sc[kk] - mx) : 0.f;
+            pr[key] = e;
+            sum += e;
+        }
+        sum = wave_sum(sum);
+        __builtin_amdgcn_wave_barrier();
+        float o = 0.f;
+        for (int key = 0; key < S; ++key) o += pr[key] * sV[key * DH + lane];
+        elem<T>::st(ctx + ((size_t)b * S + qi) * ld_ctx + h * DH + lane, o / sum);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Encoder attention on MFMA (bf16).  One block (4 waves) per (image, head).
+//   LDS:  sK  [224 keys][64 d] bf16, 128-B rows, 16-B chunks XOR-swizzled like the GEMM tiles
+//         sVt [64 d][228 keys] bf16 (V transposed; 228 = conflict-free ds_read_b64 row stride)
+//   A wave takes 32 queries at a time.  S^T = K.Q^T is computed "swapped" (keys on the MFMA rows,
+//   the query on the lane), so each lane holds all 224 scores of ITS query in registers: the row
+//   softmax is lane-local plus one exchange with lane^32.  The probability tile is then, without
+//   any data movement, the B operand of O^T = V^T.P^T (cdna_hip_programming.md §3, "An accumulator
+//   tile as the next MFMA's operand"): registers 8s..8s+7 -> bf16 = k-step s, whose k order is
+//   key = 16s + 8(j>>2) + 4(lane>>5) + (j&3); the V^T fragment is gathered in that same order.
+// ------------------------------------------------------------------------------------------------
+#define ENC_S 197
+#define ENC_SP 224
+#define ENC_VT_LD 228
+
+__global__ __launch_bounds__(256) void enc_attn_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
+                                                            int H, int ld_qkv, int ld_ctx) {
+    constexpr int DH = 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sK = smem;                                              // 224 * 128 B
+    bf16_t* sVt = reinterpret_cast<bf16_t*>(smem + ENC_SP * 128); // 64 * 228 * 2 B
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r32 = lane & 31, hh = lane >> 5;
+    const int D = H * DH;
+    const bf16_t* base = qkv + (size_t)b * ENC_S * ld_qkv + h * DH;
+
+    // ---- stage K (swizzled rows) and V^T; zero the padding keys 197..223(227)
+    for (int i = tid; i < ENC_SP * 8; i += 256) {
+        const int s = i >> 3, c = i & 7;
+        uint4 kv = make_uint4(0, 0, 0, 0);
+        if (s < ENC_S) kv = *reinterpret_cast<const uint4*>(base + (size_t)s * ld_qkv + D + c * 8);
+        *reinterpret_cast<uint4*>(sK + s * 128 + ((c ^ ((s >> 1) & 7)) << 4)) = kv;
+    }
+    for (int i = tid; i < ENC_VT_LD * 8; i += 256) {
+        const int s = i >> 3, c = i & 7;
+        uint4 vv = make_uint4(0, 0, 0, 0);
+        if (s < ENC_S) vv = *reinterpret_cast<const uint4*>(base + (size_t)s * ld_qkv + 2 * D + c * 8);
+        const unsigned w[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            sVt[(c * 8 + e) * ENC_VT_LD + s] = (bf16_t)((w[e >> 1] >> (16 * (e & 1))) & 0xffff);
+    }
+    __syncthreads();
+
+    for (int qt = wave; qt < ENC_SP / 32; qt += 4) {
+        const int q = qt * 32 + r32;
+        const int qc = q < ENC_S ? q : ENC_S - 1;   // clamp: padded queries are computed, not stored
+        // B operand of S^T = K.Q^T : lane holds Q[q][16s + 8hh .. +7]
+        bf16x8 qf[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            qf[s] = *reinterpret_cast<const bf16x8*>(base + (size_t)qc * ld_qkv + s * 16 + hh * 8);
+        f32x16 st[7];
+#pragma unroll
+        for (int kt = 0; kt < 7; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
+            const int row = kt * 32 + r32;
+            const int sw = (row >> 1) & 7;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(sK + row * 128 + (((2 * s + hh) ^ sw) << 4));
+                st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[s], st[kt], 0, 0, 0);
+            }
+        }
+        // ---- softmax over the 224 keys of this lane's query (112 here, 112 in lane^32)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 7; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (kt == 6 && key >= ENC_S) st[kt][r] = -INFINITY;
+                mx = fmaxf(mx, st[kt][r]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float c0 = 0.125f * 1.44269504088896340736f;   // scale * log2(e)
+        const float mb = mx * c0;
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 7; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = exp2f(st[kt][r] * c0 - mb);
+                st[kt][r] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 32, 64);
+        // ---- O^T[d][q] = sum_key V^T[d][key] P^T[key][q]
+        f32x16 oacc[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 7; ++kt) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8 pf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[j] = (__bf16)st[kt][8 * s + j];
+                const int key0 = kt * 32 + 16 * s + 4 * hh;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const bf16_t* vr = sVt + (dt * 32 + r32) * ENC_VT_LD + key0;
+                    const uint2 lo = *reinterpret_cast<const uint2*>(vr);       // keys key0 .. +3   (j = 0..3)
+                    const uint2 hi = *reinterpret_cast<const uint2*>(vr + 8);   // keys key0+8 .. +11 (j = 4..7)
+                    union { uint4 u; bf16x8 v; } cvt;
+                    cvt.u = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cvt.v, pf, oacc[dt], 0, 0, 0);
+                }
+            }
+        }
+        if (q < ENC_S) {
+            const float inv = 1.0f / sum;
+            bf16_t* orow = ctx + ((size_t)b * ENC_S + q) * ld_ctx + h * DH;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float o4[4] = {oacc[dt][4 * g] * inv, oacc[dt][4 * g + 1] * inv, oacc[dt][4 * g + 2] * inv,
+                                   oacc[dt][4 * g + 3] * inv};
+                    elem<bf16_t>::st4(orow + dt * 32 + 8 * g + 4 * hh, o4);   // d = 32dt + 8g + 4hh + (r&3)
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Decode-step attention (query length 1).  Block = 4 waves = 4 heads of one sequence.
+// Wave layout: lane = 8*g + c; the 8 lanes of group g read one 64-element K (or V) row, 8
+// elements (16 B in bf16) each, so one wave-instruction streams 8 whole rows = 1 KiB contiguous.
+//   q (and for SELF the new k, v) = sum of the split-K slabs of the QKV projection + bias.
+//   SELF : keys 0..L-2 from the cache, key L-1 is the new token (kept in registers and appended to
+//          the cache); L = step[b] + 1.       (TF/models/bert/modeling_bert.py:139-203)
+//   CROSS: keys 0..196 from the cross K/V computed once per crop (modeling_bert.py:206-279).
+// ------------------------------------------------------------------------------------------------
+struct DecAttnParams {
+    const float* slabs;      // [nslab][rows_pad][ldq] fp32 partial projections
+    int nslab;
+    long long slab_stride;
+    int ldq;                 // 2304 (self: q|k|v) or 768 (cross: q)
+    const float* bias;       // [ldq]
+    const void* kbase;       // self: K cache [B][H][Lmax][64] ; cross: CKV + k column offset
+    const void* vbase;
+    long long kv_batch_stride;  // elements between sequences
+    long long kv_head_stride;   // elements between heads
+    long long kv_row_stride;    // elements between keys
+    void* ctx;               // [rows][768] T
+    const int* step;         // [B] current position of every row (self)
+    int cross_len;           // 197 (cross)
+    int H;
+    float scale;
+};
+
+template <typename T, bool SELF>
+__global__ __launch_bounds__(256) void dec_attn_kernel(DecAttnParams p) {
+    constexpr int DH = 64, LMAX = 320;
+    __shared__ float s_sc[4][LMAX];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = lane >> 3, c = lane & 7;
+    const int hpb = p.H / 4;
+    const int b = blockIdx.x / hpb;
+    const int h = (blockIdx.x % hpb) * 4 + wave;
+    const int D = p.H * DH;
+    const int col = h * DH + c * 8;
+    float* sc = s_sc[wave];
+
+    float q[8], kn[8], vn[8];
+    {
+        float4 a0 = *reinterpret_cast<const float4*>(p.bias + col), a1 = *reinterpret_cast<const float4*>(p.bias + col + 4);
+        q[0] = a0.x; q[1] = a0.y; q[2] = a0.z; q[3] = a0.w; q[4] = a1.x; q[5] = a1.y; q[6] = a1.z; q[7] = a1.w;
+        if (SELF) {
+            a0 = *reinterpret_cast<const float4*>(p.bias + D + col); a1 = *reinterpret_cast<const float4*>(p.bias + D + col + 4);
+            kn[0] = a0.x; kn[1] = a0.y; kn[2] = a0.z; kn[3] = a0.w; kn[4] = a1.x; kn[5] = a1.y; kn[6] = a1.z; kn[7] = a1.w;
+            a0 = *reinterpret_cast<const float4*>(p.bias + 2 * D + col); a1 = *reinterpret_cast<const float4*>(p.bias + 2 * D + col + 4);
+            vn[0] = a0.x; vn[1] = a0.y; vn[2] = a0.z; vn[3] = a0.w; vn[4] = a1.x; vn[5] = a1.y; vn[6] = a1.z; vn[7] = a1.w;
+        }
+        for (int s = 0; s < p.nslab; ++s) {
+            const float* r = p.slabs + (size_t)s * p.slab_stride + (size_t)b * p.ldq + col;
+            float4 x0 = *reinterpret_cast<const float4*>(r), x1 = *reinterpret_cast<const float4*>(r + 4);
+            q[0] += x0.x; q[1] += x0.y; q[2] += x0.z; q[3] += x0.w; q[4] += x1.x; q[5] += x1.y; q[6] += x1.z; q[7] += x1.w;
+            if (SELF) {
+                x0 = *reinterpret_cast<const float4*>(r + D); x1 = *reinterpret_cast<const float4*>(r + D + 4);
+                kn[0] += x0.x; kn[1] += x0.y; kn[2] += x0.z; kn[3] += x0.w; kn[4] += x1.x; kn[5] += x1.y; kn[6] += x1.z; kn[7] += x1.w;
+                x0 = *reinterpret_cast<const float4*>(r + 2 * D); x1 = *reinterpret_cast<const float4*>(r + 2 * D + 4);
+                vn[0] += x0.x; vn[1] += x0.y; vn[2] += x0.z; vn[3] += x0.w; vn[4] += x1.x; vn[5] += x1.y; vn[6] += x1.z; vn[7] += x1.w;
+            }
+        }
+    }
+    const int L = SELF ? p.step[b] + 1 : p.cross_len;
+    const int Lc = SELF ? L - 1 : L;                    // keys read from memory
+    const T* kb = reinterpret_cast<const T*>(p.kbase) + (size_t)b * p.kv_batch_stride + (size_t)h * p.kv_head_stride + c * 8;
+    const T* vb = reinterpret_cast<const T*>(p.vbase) + (size_t)b * p.kv_batch_stride + (size_t)h * p.kv_head_stride + c * 8;
+    if (SELF) {
+        // the cache stores what the storage dtype can hold; attend to exactly those values
+        T* kw = const_cast<T*>(kb) + (size_t)(L - 1) * p.kv_row_stride;
+        T* vw = const_cast<T*>(vb) + (size_t)(L - 1) * p.kv_row_stride;
+        if (sizeof(T) == 2) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { kn[e] = bf2f(f2bf(kn[e])); vn[e] = bf2f(f2bf(vn[e])); }
+        }
+        if (g == 0) { elem<T>::st8(kw, kn); elem<T>::st8(vw, vn); }
+    }
+    // ---- pass 1: scores
+    float mx = -INFINITY;
+#pragma unroll 4
+    for (int k0 = 0; k0 < Lc; k0 += 8) {
+        const int key = k0 + g;
+        float part = 0.f;
+        if (key < Lc) {
+            float kv[8];
+            elem<T>::ld8(kb + (size_t)key * p.kv_row_stride, kv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) part += q[e] * kv[e];
+        }
+        part += __shfl_xor(part, 1, 64);
+        part += __shfl_xor(part, 2, 64);
+        part += __shfl_xor(part, 4, 64);
+        part *= p.scale;
+        if (key < Lc) {
+            if (c == 0) sc[key] = part;
+            mx = fmaxf(mx, part);
+        }
+    }
+    float s_new = 0.f;
+    if (SELF) {
+        float part = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part += q[e] * kn[e];
+        part += __shfl_xor(part, 1, 64);
+        part += __shfl_xor(part, 2, 64);
+        part += __shfl_xor(part, 4, 64);
+        s_new = part * p.scale;
+        mx = fmaxf(mx, s_new);
+    }
+    mx = wave_max(mx);
+    __syncthreads();
+    // ---- pass 2: exponentials (lane owns keys lane, lane+64, ...)
+    float sum = 0.f;
+    for (int key = lane; key < Lc; key += 64) {
+        const float e = expf(sc[key] - mx);
+        sc[key] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    float p_new = 0.f;
+    if (SELF) { p_new = expf(s_new - mx); sum += p_new; }
+    __syncthreads();
+    // ---- pass 3: weighted values
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int k0 = 0; k0 < Lc; k0 += 8) {
+        const int key = k0 + g;
+        if (key < Lc) {
+            float vv[8];
+            elem<T>::ld8(vb + (size_t)key * p.kv_row_stride, vv);
+            const float pk = sc[key];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += pk * vv[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float a = acc[e];
+        a += __shfl_xor(a, 8, 64);
+        a += __shfl_xor(a, 16, 64);
+        a += __shfl_xor(a, 32, 64);
+        if (SELF) a += p_new * vn[e];
+        acc[e] = a / sum;
+    }
+    if (g == 0) elem<T>::st8(reinterpret_cast<T*>(p.ctx) + (size_t)b * D + col, acc);
+}

@@ -1,0 +1,186 @@
+// Row-wise kernels of the greedy decode step (BERT decoder with post-LN residual blocks,
+// TF/models/bert/modeling_bert.py:282-293, 340-351, 466-496; greedy loop TF/generation/utils.py:
+// 2783-2973).  The skinny projections (M = batch) run as split-K GEMMs that leave fp32 partial
+// slabs; every consumer below sums the slabs in a fixed order (deterministic, unlike float
+// atomics), adds the bias and fuses the element-wise work that follows.
+#pragma once
+#include "common.h"
+
+// out = LayerNorm( [gelu]( sum_s slab_s + bias ) [+ resid] ) ; writes fp32 (next residual) and T
+// (next GEMM operand).  One wave per row of 768.
+template <typename T, int D, bool GELU>
+__global__ __launch_bounds__(256) void dec_add_ln_kernel(const float* __restrict__ slabs, int nslab, long long slab_stride,
+                                                         const float* __restrict__ bias, const float* __restrict__ resid,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float* __restrict__ out_f32, T* __restrict__ out_t, int rows, float eps) {
+    constexpr int V = D / 256;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float v[V * 4];
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const int c = i * 256 + lane * 4;
+        float4 a = *reinterpret_cast<const float4*>(bias + c);
+        for (int s = 0; s < nslab; ++s) {
+            const float4 x = *reinterpret_cast<const float4*>(slabs + (size_t)s * slab_stride + (size_t)row * D + c);
+            a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
+        }
+        if (GELU) { a.x = gelu_erf(a.x); a.y = gelu_erf(a.y); a.z = gelu_erf(a.z); a.w = gelu_erf(a.w); }
+        if (resid) {
+            const float4 r = *reinterpret_cast<const float4*>(resid + (size_t)row * D + c);
+            a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w;
+        }
+        v[4 * i] = a.x; v[4 * i + 1] = a.y; v[4 * i + 2] = a.z; v[4 * i + 3] = a.w;
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < V * 4; ++i) s += v[i];
+    const float mean = wave_sum(s) * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < V * 4; ++i) { const float d = v[i] - mean; q += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / D) + eps);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const int c = i * 256 + lane * 4;
+        const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+        const float4 b = *reinterpret_cast<const float4*>(beta + c);
+        float o[4] = {(v[4 * i] - mean) * rstd * g.x + b.x, (v[4 * i + 1] - mean) * rstd * g.y + b.y,
+                      (v[4 * i + 2] - mean) * rstd * g.z + b.z, (v[4 * i + 3] - mean) * rstd * g.w + b.w};
+        if (out_f32) *reinterpret_cast<float4*>(out_f32 + (size_t)row * D + c) = make_float4(o[0], o[1], o[2], o[3]);
+        elem<T>::st4(out_t + (size_t)row * D + c, o);
+    }
+}
+
+// out T = gelu( sum_s slab_s + bias )   (the decoder FFN's intermediate activation)
+template <typename T>
+__global__ void dec_bias_gelu_kernel(const float* __restrict__ slabs, int nslab, long long slab_stride,
+                                     const float* __restrict__ bias, T* __restrict__ out, int rows, int N) {
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= (long long)rows * N) return;
+    const int c = (int)(i % N);
+    float4 a = *reinterpret_cast<const float4*>(bias + c);
+    for (int s = 0; s < nslab; ++s) {
+        const float4 x = *reinterpret_cast<const float4*>(slabs + (size_t)s * slab_stride + i);
+        a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
+    }
+    float o[4] = {gelu_erf(a.x), gelu_erf(a.y), gelu_erf(a.z), gelu_erf(a.w)};
+    elem<T>::st4(out + i, o);
+}
+
+// Per-sequence decode state, all device resident so a decode step is a fixed launch sequence
+// (replayable as a HIP graph): no host value changes from step to step.
+struct DecState {
+    int* ids;          // [B][max_len] int32 output rows (ids[b][0] = start_id)
+    int* step;         // [B] position of the token being consumed
+    int* finished;     // [B]
+    int* len;          // [B] tokens in the row incl. start and EOS
+    int* n_unfinished; // [1]
+    const int* forced; // [B][forced_T] teacher-forced inputs (test hook) or null
+    int forced_T;
+    float* logits_out; // [B][forced_T][V] (test hook) or null
+    int ids_ld;        // row stride of ids
+    int max_len;       // generate(max_length): a row is finished when it holds max_len tokens
+    int start_id, eos_id, pad_id;
+};
+
+// End of a decode step, one block per sequence:
+//   logits = sum_s slab_s + bias  -> fp32 argmax (lowest index wins ties, like torch.argmax)
+//   finished rows emit pad_id (utils.py:2929); EOS or reaching max_len finishes a row (:2936)
+//   then the NEXT step's input embedding: LN(word[tok] + type[0] + pos[t+1])  (modeling_bert.py:98-106)
+// FIRST = true: no logits yet; emits the start token's embedding at position 0.
+template <typename T, int D, bool FIRST>
+__global__ __launch_bounds__(256) void dec_token_kernel(const float* __restrict__ slabs, int nslab, long long slab_stride,
+                                                        const float* __restrict__ vbias, int V,
+                                                        DecState st,
+                                                        const float* __restrict__ word, const float* __restrict__ type0,
+                                                        const float* __restrict__ pos, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ x_f32,
+                                                        T* __restrict__ x_t, float eps) {
+    __shared__ float s_val[4];
+    __shared__ int s_idx[4];
+    __shared__ float s_red[4];
+    __shared__ int s_tok, s_pos;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (FIRST) {
+        if (tid == 0) {
+            st.ids[(size_t)b * st.ids_ld] = st.start_id;
+            st.step[b] = 0; st.finished[b] = 0; st.len[b] = st.max_len;
+            s_tok = st.start_id; s_pos = 0;
+            if (b == 0) *st.n_unfinished = (int)gridDim.x;
+        }
+    } else {
+        const int t = st.step[b];
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int c = tid * 4; c < V; c += 1024) {
+            float4 a = *reinterpret_cast<const float4*>(vbias + c);
+            for (int s = 0; s < nslab; ++s) {
+                const float4 x = *reinterpret_cast<const float4*>(slabs + (size_t)s * slab_stride + (size_t)b * V + c);
+                a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
+            }
+            if (st.logits_out)
+                *reinterpret_cast<float4*>(st.logits_out + ((size_t)b * st.forced_T + t) * V + c) = a;
+            if (a.x > best) { best = a.x; bi = c; }
+            if (a.y > best) { best = a.y; bi = c + 1; }
+            if (a.z > best) { best = a.z; bi = c + 2; }
+            if (a.w > best) { best = a.w; bi = c + 3; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        if (lane == 0) { s_val[wave] = best; s_idx[wave] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < 4; ++w)
+                if (s_val[w] > best || (s_val[w] == best && s_idx[w] < bi)) { best = s_val[w]; bi = s_idx[w]; }
+            int fin = st.finished[b];
+            int tok = fin ? st.pad_id : bi;
+            if (st.forced) tok = (t + 1 < st.forced_T) ? st.forced[(size_t)b * st.forced_T + t + 1] : st.pad_id;
+            if (t + 1 < st.ids_ld) st.ids[(size_t)b * st.ids_ld + t + 1] = tok;
+            if (!fin && !st.forced && (tok == st.eos_id || t + 2 >= st.max_len)) {
+                st.finished[b] = 1;
+                st.len[b] = t + 2;
+                atomicSub(st.n_unfinished, 1);
+            }
+            st.step[b] = t + 1;
+            s_tok = tok; s_pos = t + 1;
+        }
+    }
+    __syncthreads();
+    const int tok = s_tok, ps = s_pos;
+    // embedding + LayerNorm of the next input, block-wide over D = 768 (3 per thread)
+    constexpr int PER = D / 256;
+    float v[PER];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int d = tid + i * 256;
+        float e = word[(size_t)tok * D + d] + type0[d];
+        e = e + pos[(size_t)ps * D + d];
+        v[i] = e; s += e;
+    }
+    s = wave_sum(s);
+    if (lane == 0) s_red[wave] = s;
+    __syncthreads();
+    const float mean = (s_red[0] + s_red[1] + s_red[2] + s_red[3]) * (1.0f / D);
+    __syncthreads();
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) { const float d = v[i] - mean; q += d * d; }
+    q = wave_sum(q);
+    if (lane == 0) s_red[wave] = q;
+    __syncthreads();
+    const float rstd = 1.0f / sqrtf((s_red[0] + s_red[1] + s_red[2] + s_red[3]) * (1.0f / D) + eps);
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int d = tid + i * 256;
+        const float o = (v[i] - mean) * rstd * gamma[d] + beta[d];
+        x_f32[(size_t)b * D + d] = o;
+        elem<T>::st(x_t + (size_t)b * D + d, o);
+    }
+}

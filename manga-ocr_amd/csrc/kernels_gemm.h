@@ -1,0 +1,207 @@
+// MFMA GEMM for the recogniser's dense layers:  C[M,N] = A[M,K] . W[N,K]^T  (+ epilogue)
+//
+// Both operands are K-contiguous (activations row-major, weights in torch.nn.Linear's
+// [out,in] layout), so A and W tiles are staged the same way.  One kernel template serves
+//   T = bf16_t : v_mfma_f32_32x32x16_bf16, fp32 accumulate             (throughput mode)
+//   T = float  : v_mfma_f32_32x32x2_f32, an exact k-ordered fmaf chain  (parity mode)
+// because a K-tile is defined in BYTES: 128 B per row (64 bf16 / 32 f32).
+//
+// Structure (cdna_hip_programming.md §5, "2-buffer glds" form):
+//   * 256 threads = 4 waves as 2x2; each wave owns a (BM/2)x(BN/2) sub-tile = TMxTN MFMA tiles.
+//   * global -> LDS by global_load_lds_dwordx4 (no VGPR round trip).  One wave-instruction
+//     writes 1 KiB = 8 rows x 128 B, lane-linear; the bank-conflict swizzle is therefore
+//     applied on the SOURCE address and on the fragment read (rule 21):
+//         16-byte chunk c of row r lives at chunk  c ^ ((r >> 1) & 7).
+//     With 128-B rows two rows share one 256-B bank row; (r>>1)&7 makes every ds_read_b128
+//     16-lane group hit 16 distinct 16-B slots (conflict-free).
+//   * double-buffered: tile t+1 is in flight while tile t is multiplied; one barrier per K-tile.
+//   * epilogue through LDS (fp32 tile) so that global stores / residual loads are full
+//     16-byte, row-contiguous accesses; bias / GELU / residual / position-embedding are fused.
+//   * blockIdx -> tile map is XCD-aware (bijective remap, §5 T1): the 8 XCDs each get a
+//     contiguous run of tiles, so tiles sharing an A row-panel share an L2.
+#pragma once
+#include "common.h"
+
+enum GemmEpilogue {
+    EPI_SLAB = 0,        // fp32 partial sums of K-slice blockIdx.z -> out[z][m][n]   (split-K, no bias)
+    EPI_BIAS = 1,        // out T   = acc + bias
+    EPI_BIAS_GELU = 2,   // out T   = gelu(acc + bias)
+    EPI_BIAS_RESID = 3,  // out f32 = (acc + bias) + resid        (out may alias resid)
+    EPI_PATCH = 4,       // patch-embed: out f32[b*197+1+p] = (acc + bias) + pos[1+p]
+    EPI_BIAS_F32 = 5     // out f32 = acc + bias
+};
+
+struct GemmParams {
+    const void* A;
+    const void* W;
+    const float* bias;
+    void* out;
+    const float* resid;
+    const float* pos;      // EPI_PATCH: [tokens][N] position embeddings
+    int M, N;              // logical output size (rows >= M are computed but not stored)
+    int lda, ldw, ldo;     // leading dimensions in elements
+    int k_per_split;       // elements of K handled by one blockIdx.z
+    long long slab_stride; // EPI_SLAB: elements between slabs
+    int ntn;               // tiles along N
+    int patches;           // EPI_PATCH: patches per image (196)
+};
+
+template <typename T, int BM, int BN, int EPI>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
+    constexpr int TM = BM / 64, TN = BN / 64;          // 32x32 MFMA tiles per wave
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    static_assert(BM * BN * 4 <= 2 * STAGE, "fp32 epilogue tile must fit the staging buffers");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r32 = lane & 31, hh = lane >> 5;
+
+    // XCD-aware bijective remap of the linear block id (8 XCDs, round-robin dispatch)
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tn = bid % p.ntn, tm = bid / p.ntn;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = blockIdx.z * p.k_per_split;
+    const int nt = p.k_per_split / (128 / (int)sizeof(T));
+
+    const char* Ab = (const char*)p.A + ((size_t)m0 * p.lda + kbeg) * sizeof(T);
+    const char* Wb = (const char*)p.W + ((size_t)n0 * p.ldw + kbeg) * sizeof(T);
+    const size_t a_row = (size_t)p.lda * sizeof(T), w_row = (size_t)p.ldw * sizeof(T);
+
+    // per-lane part of the staging addresses: lane -> (row within 8-row piece, physical chunk)
+    const int prow = lane >> 3, pchunk = lane & 7;
+
+    auto stage = [&](int t, int buf) {
+        char* sa = smem + buf * STAGE;
+        char* sb = sa + A_BYTES;
+#pragma unroll
+        for (int pc = wave; pc < BM / 8; pc += 4) {
+            const int row = pc * 8 + prow;
+            const int c = pchunk ^ ((row >> 1) & 7);
+            glds16(Ab + (size_t)row * a_row + (size_t)t * 128 + c * 16, sa + pc * 1024);
+        }
+#pragma unroll
+        for (int pc = wave; pc < BN / 8; pc += 4) {
+            const int row = pc * 8 + prow;
+            const int c = pchunk ^ ((row >> 1) & 7);
+            glds16(Wb + (size_t)row * w_row + (size_t)t * 128 + c * 16, sb + pc * 1024);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    int rowA[TM], rowB[TN], swA[TM], swB[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) { rowA[i] = wm * (BM / 2) + i * 32 + r32; swA[i] = (rowA[i] >> 1) & 7; }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { rowB[j] = wn * (BN / 2) + j * 32 + r32; swB[j] = (rowB[j] >> 1) & 7; }
+
+    stage(0, 0);
+    for (int t = 0; t < nt; ++t) {
+        // tile t has landed (each wave drains its own DMA, the barrier covers the others') and
+        // every wave has finished reading the buffer tile t+1 is about to overwrite
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < nt) stage(t + 1, (t + 1) & 1);
+        const char* sa = smem + (t & 1) * STAGE;
+        const char* sb = sa + A_BYTES;
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int c = 2 * s + hh;
+                bf16x8 a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = *(const bf16x8*)(sa + rowA[i] * 128 + ((c ^ swA[i]) << 4));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = *(const bf16x8*)(sb + rowB[j] * 128 + ((c ^ swB[j]) << 4));
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int k = 2 * s + hh;            // A[i=lane&31][k=lane>>5] of a 32x32x2 step
+                const int c = k >> 2, o = (k & 3) * 4;
+                float a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = *(const float*)(sa + rowA[i] * 128 + ((c ^ swA[i]) << 4) + o);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = *(const float*)(sb + rowB[j] * 128 + ((c ^ swB[j]) << 4) + o);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: accumulators -> LDS (fp32 [BM][BN]) -> fused epilogue -> 16-byte global stores
+    __syncthreads();
+    float* sC = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                // C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+                const int row = wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const int col = wn * (BN / 2) + j * 32 + r32;
+                sC[row * BN + col] = acc[i][j][r];
+            }
+    __syncthreads();
+
+    constexpr int TPR = BN / 4;      // threads per output row (4 columns each)
+    constexpr int RPI = 256 / TPR;   // rows per pass
+    const int col = (tid % TPR) * 4;
+    const int n = n0 + col;
+    float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (EPI != EPI_SLAB) {
+        const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+        bias4[0] = bv.x; bias4[1] = bv.y; bias4[2] = bv.z; bias4[3] = bv.w;
+    }
+#pragma unroll 4
+    for (int it = 0; it < BM / RPI; ++it) {
+        const int row = it * RPI + tid / TPR;
+        const int m = m0 + row;
+        if (m >= p.M) continue;
+        const float4 cv = *reinterpret_cast<const float4*>(&sC[row * BN + col]);
+        float v[4] = {cv.x + bias4[0], cv.y + bias4[1], cv.z + bias4[2], cv.w + bias4[3]};
+        if constexpr (EPI == EPI_SLAB) {
+            float* o = reinterpret_cast<float*>(p.out) + (size_t)blockIdx.z * p.slab_stride + (size_t)m * p.ldo + n;
+            *reinterpret_cast<float4*>(o) = cv;
+        } else if constexpr (EPI == EPI_BIAS) {
+            elem<T>::st4(reinterpret_cast<T*>(p.out) + (size_t)m * p.ldo + n, v);
+        } else if constexpr (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+            elem<T>::st4(reinterpret_cast<T*>(p.out) + (size_t)m * p.ldo + n, v);
+        } else if constexpr (EPI == EPI_BIAS_RESID) {
+            const float4 rv = *reinterpret_cast<const float4*>(p.resid + (size_t)m * p.ldo + n);
+            float* o = reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n;
+            *reinterpret_cast<float4*>(o) = make_float4(v[0] + rv.x, v[1] + rv.y, v[2] + rv.z, v[3] + rv.w);
+        } else if constexpr (EPI == EPI_PATCH) {
+            const int b = m / p.patches, pi = m - b * p.patches;
+            const float4 pv = *reinterpret_cast<const float4*>(p.pos + (size_t)(1 + pi) * p.N + n);
+            float* o = reinterpret_cast<float*>(p.out) + ((size_t)b * (p.patches + 1) + 1 + pi) * p.ldo + n;
+            *reinterpret_cast<float4*>(o) = make_float4(v[0] + pv.x, v[1] + pv.y, v[2] + pv.z, v[3] + pv.w);
+        } else {  // EPI_BIAS_F32
+            float* o = reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n;
+            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}

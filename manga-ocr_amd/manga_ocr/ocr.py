@@ -1,0 +1,163 @@
+"""``MangaOcr`` - the drop-in for the recogniser the reference application constructs once
+(``src/ui/main_window.py:3394``: ``MangaOcr()``) and calls per crop from many threads
+(``src/ui/main_window.py:9801``: ``self.manga_ocr_reader(pil_img) -> str``).
+
+Same call surface as the ``manga-ocr`` package [RECALL]: ``MangaOcr(pretrained_model_name_or_path=
+'kha-white/manga-ocr-base', force_cpu=False)``, ``__call__(PIL.Image | str | Path) -> str`` and
+``ValueError`` for anything else.  Behind it: the HIP engine (libmocr_hip.so) on this
+process's MI355X.  Concurrent callers (the reference runs up to 15 QueueProcessorWorker threads
+on one shared instance, ``src/core/workers.py:209-247``) are coalesced into one batch per decode
+instead of being serialised.  There is no CPU path: without the library or a GPU the constructor
+raises, which the application already handles (``main_window.py:3396-3398``).
+"""
+from __future__ import annotations
+
+import glob
+import os
+import threading
+import time
+from concurrent.futures import Future
+from pathlib import Path
+from typing import List, Optional, Sequence, Union
+
+import numpy as np
+
+from .engine import Engine
+from .text import Vocab, find_vocab, ids_to_text
+from .weights import DEFAULT_SPEC, load_checkpoint, synthetic_weights
+
+DEFAULT_MODEL = "kha-white/manga-ocr-base"
+
+
+def _resolve_model_dir(name_or_path: str) -> Optional[str]:
+    """A local directory, $MANGA_OCR_MODEL_DIR, or an already-downloaded HF cache snapshot.
+    Never touches the network."""
+    cands = [name_or_path, os.environ.get("MANGA_OCR_MODEL_DIR", "")]
+    hub = os.environ.get("HF_HOME", os.path.join(os.path.expanduser("~"), ".cache", "huggingface"))
+    cands += sorted(glob.glob(os.path.join(hub, "hub", "models--" + name_or_path.replace("/", "--"), "snapshots", "*")))
+    for c in cands:
+        if c and os.path.isdir(c) and os.path.exists(os.path.join(c, "config.json")):
+            return c
+    return None
+
+
+def to_gray224(img, size: int = 224) -> np.ndarray:
+    """PIL image -> uint8 [224,224]: ``convert('L')`` then the HF image processor's
+    ``resize((224,224), BILINEAR)`` (identity for 224x224 crops).  Equivalent to the
+    reference's convert('L').convert('RGB') + resize because the three channels are equal."""
+    from PIL import Image
+    g = img.convert("L")
+    if g.size != (size, size):
+        g = g.resize((size, size), Image.BILINEAR)
+    return np.asarray(g, dtype=np.uint8)
+
+
+class _Batcher:
+    """Coalesces concurrent single-crop requests into engine batches (FIFO, per-request error
+    isolation like the reference's worker loop, ``src/core/workers.py:241-244``)."""
+
+    def __init__(self, engine: Engine, max_batch: int, timeout_ms: float):
+        self.engine, self.max_batch, self.timeout = engine, max_batch, timeout_ms / 1000.0
+        self._q: List = []
+        self._cv = threading.Condition()
+        self._stop = False
+        self._thread = threading.Thread(target=self._run, name="mocr-batcher", daemon=True)
+        self._thread.start()
+
+    def submit(self, gray: np.ndarray) -> Future:
+        f: Future = Future()
+        with self._cv:
+            if self._stop:
+                raise RuntimeError("MangaOcr is closed")
+            self._q.append((gray, f))
+            self._cv.notify()
+        return f
+
+    def _run(self):
+        while True:
+            with self._cv:
+                while not self._q and not self._stop:
+                    self._cv.wait()
+                if self._stop and not self._q:
+                    return
+                deadline = time.monotonic() + self.timeout
+                while len(self._q) < self.max_batch and not self._stop:
+                    left = deadline - time.monotonic()
+                    if left <= 0:
+                        break
+                    self._cv.wait(left)
+                batch, self._q = self._q[:self.max_batch], self._q[self.max_batch:]
+            try:
+                ids, lens = self.engine.recognize(np.stack([g for g, _ in batch]))
+                for i, (_, f) in enumerate(batch):
+                    f.set_result(ids[i, :lens[i]].copy())
+            except BaseException as exc:  # every waiting caller gets the error; the loop lives on
+                for _, f in batch:
+                    if not f.done():
+                        f.set_exception(exc)
+
+    def close(self):
+        with self._cv:
+            self._stop = True
+            self._cv.notify_all()
+        self._thread.join(timeout=5)
+
+
+class MangaOcr:
+    def __init__(self, pretrained_model_name_or_path: str = DEFAULT_MODEL, force_cpu: bool = False, *,
+                 dtype: Optional[str] = None, device: Optional[int] = None, max_batch: Optional[int] = None,
+                 batch_timeout_ms: float = 2.0, synthetic_seed: Optional[int] = None):
+        if force_cpu:
+            raise RuntimeError("this MangaOcr is the MI355X engine: there is no CPU path (force_cpu=True is not supported)")
+        dtype = dtype or os.environ.get("MANGA_OCR_DTYPE", "bf16")
+        device = int(os.environ.get("LOCAL_RANK", "0")) if device is None else device
+        max_batch = int(max_batch or os.environ.get("MANGA_OCR_MAX_BATCH", "64"))
+        if synthetic_seed is None and os.environ.get("MANGA_OCR_SYNTHETIC"):
+            synthetic_seed = int(os.environ["MANGA_OCR_SYNTHETIC"])
+        if synthetic_seed is not None:
+            spec, weights, vocab = DEFAULT_SPEC, synthetic_weights(synthetic_seed), Vocab.synthetic(DEFAULT_SPEC.vocab)
+        else:
+            model_dir = _resolve_model_dir(str(pretrained_model_name_or_path))
+            if model_dir is None:
+                raise FileNotFoundError(
+                    f"no local copy of '{pretrained_model_name_or_path}' (looked at the path, $MANGA_OCR_MODEL_DIR and the "
+                    "HF cache; this build never downloads). Set MANGA_OCR_SYNTHETIC=<seed> for synthetic weights.")
+            spec, weights = load_checkpoint(model_dir)
+            vp = find_vocab(model_dir)
+            if vp is None:
+                raise FileNotFoundError(f"vocab.txt not found in {model_dir}")
+            vocab = Vocab.from_file(vp)
+            if len(vocab) != spec.vocab:
+                raise ValueError(f"vocab.txt has {len(vocab)} entries, config says {spec.vocab}")
+        self.spec, self.vocab = spec, vocab
+        self.engine = Engine(weights, spec, dtype=dtype, device=device, max_batch=max_batch)
+        self._batcher = _Batcher(self.engine, max_batch, batch_timeout_ms)
+        # same warm-up the reference's recogniser does in its constructor (one inference)
+        self.recognize_ids([np.zeros((spec.image_size, spec.image_size), dtype=np.uint8)])
+
+    # ------------------------------------------------------------------ reference call surface
+    def __call__(self, img_or_path) -> str:
+        from PIL import Image
+        if isinstance(img_or_path, (str, Path)):
+            img = Image.open(img_or_path)
+        elif isinstance(img_or_path, Image.Image):
+            img = img_or_path
+        else:
+            raise ValueError(f"img_or_path must be a path or PIL.Image, instead got: {img_or_path}")
+        ids = self._batcher.submit(to_gray224(img, self.spec.image_size)).result()
+        return ids_to_text(self.vocab, ids)
+
+    # ------------------------------------------------------------------ batch surface (callers that hold many crops)
+    def recognize_ids(self, grays: Sequence[np.ndarray]) -> List[np.ndarray]:
+        ids, lens = self.engine.recognize(np.stack(list(grays)))
+        return [ids[i, :lens[i]].copy() for i in range(len(lens))]
+
+    def recognize_batch(self, images: Sequence) -> List[str]:
+        """All crops of a page (or chapter) at once - what ``_collect_manga_detections``
+        (``src/ui/main_window.py:9462-9476``) does one region at a time."""
+        grays = [to_gray224(im, self.spec.image_size) for im in images]
+        return [ids_to_text(self.vocab, r) for r in self.recognize_ids(grays)]
+
+    def close(self) -> None:
+        self._batcher.close()
+        self.engine.close()

@@ -1,0 +1,126 @@
+"""-m gpu: every HIP kernel class against a float64 numpy / torch-fp32 statement of the same op,
+called through the C ABI's operator hooks.  Device memory comes from torch (plumbing only)."""
+import numpy as np
+import pytest
+
+from gpu_util import bf16_round, engine, report
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+EPI_SLAB, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_PATCH, EPI_BIAS_F32 = range(6)
+
+
+def _dev(a, dtype):
+    t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return t.to(torch.bfloat16) if dtype == "bf16" else t
+
+
+def _gelu(x):
+    from scipy.special import erf
+    return 0.5 * x * (1.0 + erf(x / np.sqrt(2.0)))
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("tile,M,N,K", [(128, 256, 256, 128), (128, 384, 768, 768), (64, 64, 768, 768),
+                                         (64, 192, 128, 3072), (128, 394, 2304, 768)])
+@pytest.mark.parametrize("epi", [EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_BIAS_F32])
+def test_gemm_epilogues(dtype, tile, M, N, K, epi):
+    eng = engine(dtype)
+    rs = np.random.RandomState(M + N + K + epi)
+    Mp = (M + tile - 1) // tile * tile                       # the kernel stages whole tiles of A
+    A = rs.standard_normal((Mp, K)).astype(np.float32)
+    W = (rs.standard_normal((N, K)) * 0.05).astype(np.float32)
+    bias = rs.standard_normal(N).astype(np.float32)
+    resid = rs.standard_normal((M, N)).astype(np.float32)
+    if dtype == "bf16":
+        A, W = bf16_round(A), bf16_round(W)
+    ref = A[:M].astype(np.float64) @ W.astype(np.float64).T + bias
+    if epi == EPI_BIAS_GELU:
+        ref = _gelu(ref)
+    if epi == EPI_BIAS_RESID:
+        ref = ref + resid
+    dA, dW = _dev(A, dtype), _dev(W, dtype)
+    dB = torch.from_numpy(bias).cuda()
+    out_f32 = epi in (EPI_BIAS_RESID, EPI_BIAS_F32)
+    dO = torch.full((M, N), float("nan"), device="cuda",
+                    dtype=torch.float32 if (out_f32 or dtype == "fp32") else torch.bfloat16)
+    dR = torch.from_numpy(resid).cuda() if epi == EPI_BIAS_RESID else None
+    torch.cuda.synchronize()
+    eng.op_gemm(dA, dW, dB, dO, dR, M, N, K, epi, tile=tile, split_k=1)
+    got = dO.float().cpu().numpy().astype(np.float64)
+    scale = np.abs(ref).max()
+    err = np.abs(got - ref).max() / scale
+    tol = 2e-6 * np.sqrt(K) if (dtype == "fp32") else (1e-5 if out_f32 else 6e-3)
+    report(f"gemm {dtype} tile{tile} M{M} N{N} K{K} epi{epi}: max rel err {err:.3e} (tol {tol:.1e})")
+    assert np.isfinite(got).all()
+    assert err <= tol
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("M,N,K,split", [(64, 768, 768, 12), (37, 2304, 768, 4), (128, 768, 3072, 16), (64, 6144, 768, 2)])
+def test_gemm_split_k_slabs(dtype, M, N, K, split):
+    eng = engine(dtype)
+    rs = np.random.RandomState(split)
+    Mp = (M + 63) // 64 * 64
+    A = rs.standard_normal((Mp, K)).astype(np.float32)
+    W = (rs.standard_normal((N, K)) * 0.05).astype(np.float32)
+    if dtype == "bf16":
+        A, W = bf16_round(A), bf16_round(W)
+    dA, dW = _dev(A, dtype), _dev(W, dtype)
+    dO = torch.full((split, M, N), float("nan"), device="cuda", dtype=torch.float32)
+    torch.cuda.synchronize()
+    eng.op_gemm(dA, dW, None, dO, None, M, N, K, EPI_SLAB, tile=64, split_k=split)
+    slabs = dO.cpu().numpy().astype(np.float64)
+    ks = K // split
+    worst = 0.0
+    for z in range(split):
+        ref = A[:M, z * ks:(z + 1) * ks].astype(np.float64) @ W[:, z * ks:(z + 1) * ks].astype(np.float64).T
+        worst = max(worst, np.abs(slabs[z] - ref).max() / np.abs(ref).max())
+    report(f"gemm split-K {dtype} M{M} N{N} K{K} split{split}: worst slab rel err {worst:.3e}")
+    assert worst <= 2e-5
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_layernorm(dtype):
+    eng = engine(dtype)
+    rs = np.random.RandomState(5)
+    M = 403
+    x = (rs.standard_normal((M, 768)) * 3 + 0.7).astype(np.float32)
+    g = (1 + 0.1 * rs.standard_normal(768)).astype(np.float32)
+    b = (0.1 * rs.standard_normal(768)).astype(np.float32)
+    ref = torch.nn.functional.layer_norm(torch.from_numpy(x), (768,), torch.from_numpy(g), torch.from_numpy(b), 1e-12).numpy()
+    dO = torch.full((M, 768), float("nan"), device="cuda", dtype=torch.float32 if dtype == "fp32" else torch.bfloat16)
+    dx, dg, db = (torch.from_numpy(a).cuda() for a in (x, g, b))
+    torch.cuda.synchronize()
+    eng.op_layernorm(dx, dg, db, dO, M)
+    got = dO.float().cpu().numpy()
+    err = np.abs(got - ref).max()
+    tol = 2e-5 if dtype == "fp32" else 2e-2
+    report(f"layernorm {dtype}: max abs err {err:.3e}")
+    assert err <= tol
+
+
+@pytest.mark.parametrize("dtype,impl", [("fp32", 0), ("bf16", 0), ("bf16", 1)])
+def test_encoder_attention(dtype, impl):
+    eng = engine(dtype)
+    rs = np.random.RandomState(11 + impl)
+    n, S, H, dh = 3, 197, 12, 64
+    qkv = (rs.standard_normal((n * S, 3 * H * dh)) * 1.5).astype(np.float32)
+    if dtype == "bf16":
+        qkv = bf16_round(qkv)
+    t = torch.from_numpy(qkv).view(n, S, 3, H, dh).permute(2, 0, 3, 1, 4).double()
+    s = torch.matmul(t[0], t[1].transpose(-1, -2)) * 0.125
+    ref = torch.matmul(torch.softmax(s, dim=-1), t[2]).permute(0, 2, 1, 3).reshape(n * S, H * dh).numpy()
+    dQ = _dev(qkv, dtype)
+    pad = torch.zeros((256, 3 * H * dh), device="cuda", dtype=dQ.dtype)      # rows the kernels may touch past n*S: none
+    dQ = torch.cat([dQ, pad]).contiguous()
+    dC = torch.full((n * S, H * dh), float("nan"), device="cuda", dtype=dQ.dtype)
+    torch.cuda.synchronize()
+    eng.op_enc_attention(dQ, dC, n, impl)
+    got = dC.float().cpu().numpy().astype(np.float64)
+    err = np.abs(got - ref).max()
+    tol = 5e-6 if dtype == "fp32" else 2e-2
+    report(f"enc attention {dtype} impl{impl}: max abs err {err:.3e} (|ref| max {np.abs(ref).max():.2f})")
+    assert np.isfinite(got).all()
+    assert err <= tol

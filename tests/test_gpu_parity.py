@@ -1,0 +1,197 @@
+"""-m gpu: the HIP path, called through the C ABI, against the CPU oracle and the committed
+golden vectors (tests/golden, generated from the transformers modules).
+
+Tolerances (BASELINE.json north_star): fp32 engine - logits within 1e-3 of the reference CPU path,
+token ids identical (a divergence is accepted only where the oracle's own top-2 margin is below
+the logit tolerance, i.e. a numerical tie).  bf16 engine - same structure, tolerances stated
+per test and the measured error written to gpurun_out/parity_report.txt.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from gpu_util import assert_ids_match_up_to_ties, crops, engine, oracle, report
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+LOGIT_TOL = 1e-3
+
+
+def _dgray(gray):
+    t = torch.from_numpy(gray).cuda()
+    torch.cuda.synchronize()
+    return t
+
+
+@pytest.fixture(scope="module")
+def ref4():
+    """Oracle encoder output + greedy ids/logits for 4 seeded crops (max_len 48)."""
+    o = oracle()
+    gray = crops(1234, 4)
+    enc = o.encode(o.preprocess_gray(gray))
+    ids, logits = o.generate(enc, max_len=48, return_logits=True)
+    return dict(gray=gray, enc=enc.numpy(), ids=ids, logits=logits)
+
+
+def test_fp32_encoder_matches_oracle_and_golden(ref4, golden_dir):
+    eng = engine("fp32")
+    got = eng.encode(_dgray(ref4["gray"]), 4)
+    err = np.abs(got - ref4["enc"]).max()
+    report(f"encoder fp32 vs oracle: max abs err {err:.3e}")
+    assert err <= 2e-4
+    g = np.load(os.path.join(golden_dir, "encoder_seed0.npz"))
+    gerr = np.abs(got[:, g["tok_rows"], :] - g["final_rows"]).max()
+    report(f"encoder fp32 vs transformers golden rows: max abs err {gerr:.3e}")
+    assert gerr <= 2e-4
+
+
+def test_bf16_encoder_close_to_oracle(ref4):
+    for flags, name in ((0, "mfma attention"), (1, "valu attention")):
+        eng = engine("bf16", flags=flags)
+        got = eng.encode(_dgray(ref4["gray"]), 4)
+        d = np.abs(got - ref4["enc"])
+        report(f"encoder bf16 ({name}) vs oracle: max abs err {d.max():.3e}, mean abs err {d.mean():.3e}")
+        assert np.isfinite(got).all()
+        assert d.max() <= 0.25 and d.mean() <= 0.02
+
+
+def test_fp32_teacher_forced_logits_within_1e3(ref4, golden_dir):
+    eng = engine("fp32")
+    forced = ref4["ids"][:, :-1].astype(np.int32)            # inputs of the 47 steps
+    got = eng.decode_logits(_dgray(ref4["gray"]), 4, forced)
+    err = np.abs(got - ref4["logits"]).max()
+    report(f"teacher-forced logits fp32 vs oracle: max abs err {err:.3e} over {got.shape}")
+    assert err <= LOGIT_TOL
+    g = np.load(os.path.join(golden_dir, "decoder_seed0.npz"))
+    gerr = np.abs(got[:, :, g["vocab_cols"]] - g["logits_cols"]).max()
+    report(f"teacher-forced logits fp32 vs transformers golden columns: max abs err {gerr:.3e}")
+    assert gerr <= LOGIT_TOL
+    assert (got.argmax(-1) == ref4["logits"].argmax(-1)).mean() == 1.0
+
+
+def test_bf16_teacher_forced_logits(ref4):
+    eng = engine("bf16")
+    forced = ref4["ids"][:, :-1].astype(np.int32)
+    got = eng.decode_logits(_dgray(ref4["gray"]), 4, forced)
+    d = np.abs(got - ref4["logits"])
+    agree = (got.argmax(-1) == ref4["logits"].argmax(-1)).mean()
+    report(f"teacher-forced logits bf16 vs oracle: max abs err {d.max():.3e}, mean {d.mean():.3e}, argmax agreement {agree:.4f}")
+    assert d.max() <= 0.15 and agree >= 0.9
+
+
+def test_fp32_greedy_ids_match_golden(ref4, golden_dir):
+    g = np.load(os.path.join(golden_dir, "decoder_seed0.npz"))
+    eng = engine("fp32")
+    ids, lens = eng.recognize_gray(ref4["gray"], max_len=48)
+    gap = np.sort(ref4["logits"], axis=-1)
+    gap = gap[..., -1] - gap[..., -2]
+    ties = assert_ids_match_up_to_ties(ids[:, :48], g["ids_len48"], lambda b, t: gap[b, t], LOGIT_TOL, "fp32 greedy len48")
+    report(f"fp32 greedy ids (max_len 48) vs transformers golden: {'identical' if ties == 0 else f'{ties} tie-divergences'}")
+    assert (ids[:, 48:] == 0).all() and (lens == 48).all()
+
+
+def test_fp32_greedy_full_length_matches_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "decoder_seed0.npz"))
+    eng = engine("fp32")
+    o = oracle()
+    gray = crops(1234, 2)
+    ids, lens = eng.recognize(gray)                           # the full hot path, max_len 300
+    want = g["ids_len300"]
+
+    def gap_at(b, t):
+        enc = o.encode(o.preprocess_gray(gray[b:b + 1]))
+        _, lg = o.generate(enc, return_logits=True, forced_ids=want[b:b + 1, :t + 1])
+        s = np.sort(lg[0, t])
+        return s[-1] - s[-2]
+
+    ties = assert_ids_match_up_to_ties(ids, want, gap_at, LOGIT_TOL, "fp32 greedy len300")
+    report(f"fp32 greedy ids (max_len 300) vs transformers golden: {'identical' if ties == 0 else f'{ties} tie-divergences'}")
+    assert ids.shape == (2, 300) and (lens == 300).all()
+
+
+def test_fp32_early_eos_rows_and_padding(golden_dir):
+    """Rows that emit EOS are padded with pad_id afterwards and report their length."""
+    g = np.load(os.path.join(golden_dir, "early_eos_seed1.npz"))
+    want = g["ids"]
+    eng = engine("fp32", seed=1, eos_bias=1.1)
+    o = oracle(seed=1, eos_bias=1.1)
+    gray = crops(4321, 6)
+    ids, lens = eng.recognize(gray)
+
+    def gap_at(b, t):
+        enc = o.encode(o.preprocess_gray(gray[b:b + 1]))
+        _, lg = o.generate(enc, return_logits=True, forced_ids=want[b:b + 1, :t + 1])
+        s = np.sort(lg[0, t])
+        return s[-1] - s[-2]
+
+    L = want.shape[1]
+    ties = assert_ids_match_up_to_ties(ids[:, :L], want, gap_at, LOGIT_TOL, "fp32 early-EOS")
+    if ties == 0:
+        assert (ids[:, L:] == 0).all()
+        for b in range(6):
+            hit = np.nonzero(want[b, 1:] == 3)[0]
+            assert lens[b] == (hit[0] + 2 if hit.size else 300)
+            assert (ids[b, lens[b]:] == 0).all()
+    report(f"fp32 early-EOS rows vs transformers golden: lens {lens.tolist()}, ties {ties}")
+
+
+def test_rgb_input_uses_pillow_luminance():
+    from oracle import pil_ops
+    eng = engine("fp32")
+    rs = np.random.RandomState(3)
+    rgb = rs.randint(0, 256, size=(2, 224, 224, 3), dtype=np.uint8)
+    ids_rgb, _ = eng.recognize(rgb)
+    ids_l, _ = eng.recognize(pil_ops.rgb_to_l(rgb))
+    np.testing.assert_array_equal(ids_rgb, ids_l)
+
+
+def test_batch_larger_than_max_batch_and_determinism():
+    eng = engine("bf16")
+    gray = crops(77, 11)                                      # max_batch is 8 -> two chunks
+    a, la = eng.recognize_gray(gray, max_len=24)
+    b, lb = eng.recognize_gray(gray, max_len=24)
+    np.testing.assert_array_equal(a, b)
+    c, _ = eng.recognize_gray(gray[8:], max_len=24)
+    np.testing.assert_array_equal(a[8:], c)                   # a row's result does not depend on its batch
+
+
+def test_device_resident_entry_point_matches_host_entry_point():
+    eng = engine("bf16", flags=4)                             # NO_EARLY_EXIT: the async path runs all steps
+    gray = crops(5, 3)
+    ids_h, len_h = eng.recognize(gray)
+    d_gray = _dgray(gray)
+    d_ids = torch.zeros((3, 300), dtype=torch.int32, device="cuda")
+    d_len = torch.zeros(3, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    eng.recognize_device(d_gray, 3, d_ids, d_len)
+    eng.synchronize()
+    np.testing.assert_array_equal(d_ids.cpu().numpy(), ids_h)
+    np.testing.assert_array_equal(d_len.cpu().numpy(), len_h)
+
+
+def test_mangaocr_call_surface_and_thread_batching():
+    """The reference's contract: MangaOcr()(PIL.Image) -> str, ValueError otherwise, callable
+    concurrently from worker threads (src/core/workers.py:209-247)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from PIL import Image
+
+    from manga_ocr import MangaOcr
+    from manga_ocr.text import ids_to_text
+    m = MangaOcr(synthetic_seed=0, dtype="fp32", max_batch=8)
+    try:
+        gray = crops(2024, 6)
+        imgs = [Image.fromarray(np.stack([g] * 3, -1), mode="RGB") for g in gray]
+        with ThreadPoolExecutor(6) as ex:
+            texts = list(ex.map(m, imgs))
+        want = [ids_to_text(m.vocab, r) for r in m.recognize_ids(list(gray))]
+        assert texts == want and all(isinstance(t, str) and t for t in texts)
+        assert m.recognize_batch(imgs) == want
+        big = Image.fromarray(np.random.RandomState(1).randint(0, 256, (301, 117, 3), dtype=np.uint8), mode="RGB")
+        assert isinstance(m(big), str)                         # non-224 crops go through the PIL-exact resize
+        with pytest.raises(ValueError):
+            m(np.zeros((224, 224, 3), dtype=np.uint8))
+    finally:
+        m.close()

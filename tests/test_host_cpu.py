@@ -1,0 +1,102 @@
+"""CPU: host logic - C-ABI library loads and exports every declared symbol, weight spec, text
+post-processing, and that the product path fails loudly without a GPU."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as entry
+from manga_ocr import _capi, text
+from manga_ocr.weights import (DEFAULT_SPEC, canonical_name, check_weights, spec_from_hf_config, synthetic_weights,
+                               tensor_table)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    entry.build()
+    return _capi.load_library()
+
+
+def test_library_exports_every_symbol_of_the_header(lib):
+    hdr = open(os.path.join(ROOT, "include", "mocr.h")).read()
+    declared = set(re.findall(r"\b(mocr_[a-z_0-9]+)\s*\(", hdr))
+    declared -= {"mocr_engine", "mocr_config", "mocr_kernel_stat"}
+    assert declared == set(_capi.SYMBOLS), declared ^ set(_capi.SYMBOLS)
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.mocr_abi_version() == 1
+
+
+def test_config_struct_matches_header():
+    hdr = open(os.path.join(ROOT, "include", "mocr.h")).read()
+    body = hdr[hdr.index("typedef struct mocr_config {"):hdr.index("} mocr_config;")]
+    fields = re.findall(r"^\s*(?:int32_t|float)\s+(\w+);", body, flags=re.M)
+    assert fields == [f[0] for f in _capi.MocrConfig._fields_]
+
+
+def test_no_gpu_means_loud_failure(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from manga_ocr.engine import Engine
+    with pytest.raises(_capi.MocrError):
+        Engine(synthetic_weights(0), DEFAULT_SPEC, dtype="bf16", max_batch=1)
+
+
+def test_bad_config_is_rejected_without_touching_a_gpu(lib):
+    import ctypes as C
+    cfg = _capi.MocrConfig(struct_size=4)
+    h = C.c_void_p()
+    assert lib.mocr_create(C.byref(cfg), C.byref(h)) == -1 and not h.value
+    assert lib.mocr_set_tensor(None, b"x", None, None, 0) == -1
+
+
+def test_synthetic_weights_are_deterministic_and_complete():
+    a, b = synthetic_weights(0), synthetic_weights(0)
+    check_weights(a)
+    assert len(a) == len(tensor_table()) == 4 + 12 * 16 + 2 + 5 + 2 * 26 + 6
+    for k in a:
+        np.testing.assert_array_equal(a[k], b[k])
+    assert sum(v.size for v in a.values()) == 111_005_952 - 590_592 + 6144 * 768  # HF count, minus the unused pooler, plus the untied head
+    c = synthetic_weights(1)
+    assert not np.array_equal(a["encoder.layernorm.weight"], c["encoder.layernorm.weight"])
+    # frozen stream: first values of the first tensor never change
+    np.testing.assert_allclose(a["encoder.embeddings.cls_token"].ravel()[:3],
+                               0.02 * np.random.RandomState(0).standard_normal(3), rtol=1e-6)
+    e = synthetic_weights(1, eos_bias=1.1)
+    d = e["decoder.cls.predictions.decoder.bias"] - c["decoder.cls.predictions.decoder.bias"]
+    assert d[3] == pytest.approx(1.1) and np.count_nonzero(d) == 1
+
+
+def test_checkpoint_key_renames_and_config_checks():
+    assert canonical_name("encoder.encoder.layer.3.attention.attention.query.weight") == "encoder.layers.3.attention.q_proj.weight"
+    assert canonical_name("encoder.encoder.layer.11.output.dense.bias") == "encoder.layers.11.mlp.fc2.bias"
+    assert canonical_name("encoder.encoder.layer.0.layernorm_before.weight") == "encoder.layers.0.layernorm_before.weight"
+    assert canonical_name("decoder.bert.encoder.layer.1.output.dense.bias") == "decoder.bert.encoder.layer.1.output.dense.bias"
+    cfg = {"encoder": {}, "decoder": {"vocab_size": 6144, "num_hidden_layers": 2}, "decoder_start_token_id": 2,
+           "eos_token_id": 3, "pad_token_id": 0, "max_length": 300}
+    assert spec_from_hf_config(cfg) == DEFAULT_SPEC
+    with pytest.raises(ValueError):
+        spec_from_hf_config({**cfg, "num_beams": 4})
+
+
+def test_post_process_known_answers():
+    # spec-derived cases ([RECALL] of manga_ocr.post_process + jaconv.h2z tables)
+    assert text.post_process("ｱ ｲ ｳ") == "アイウ"
+    assert text.post_process("ｶﾞｷﾞ ﾊﾟ") == "ガギパ"
+    assert text.post_process("abc 123!?") == "ａｂｃ１２３！？"
+    assert text.post_process("あ…い") == "あ．．．い"
+    assert text.post_process("あ・・・い・う") == "あ．．．い・う"
+    assert text.post_process("え . . 。") == "え．．。"
+    assert len(text._HALF_ASCII) == len(text._FULL_ASCII) and len(text._HALF_KANA) == len(text._FULL_KANA)
+
+
+def test_vocab_decode_skips_special_tokens_and_joins_wordpieces():
+    v = text.Vocab(["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]", "日", "本", "##語", "a"])
+    assert v.decode([2, 5, 6, 7, 3, 0, 0]) == "日 本語"
+    assert text.ids_to_text(v, [2, 5, 6, 7, 8, 3, 0]) == "日本語ａ"
+    s = text.Vocab.synthetic(6144)
+    assert len(s) == 6144 and text.ids_to_text(s, [2, 5, 6, 3]) == "一丁"
