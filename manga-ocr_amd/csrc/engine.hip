@@ -19,6 +19,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "../../include/mocr.h"
@@ -95,6 +96,8 @@ struct mocr_engine {
     int *ids = nullptr, *step = nullptr, *finished = nullptr, *len = nullptr, *n_unf = nullptr;
     int* forced = nullptr; float* logits_dbg = nullptr; size_t forced_cap = 0, logits_cap = 0;
     int* h_pinned = nullptr;
+    // decode-step HIP graphs, keyed by (rows, max_len, steps per graph)
+    std::map<std::tuple<int, int, int>, hipGraphExec_t> graphs;
     // profiling
     bool prof_on = false;
     std::vector<std::string> knames;
@@ -165,8 +168,6 @@ void launch_gemm_t(mocr_engine* e, const GemmParams& p0, int split) {
     p.ntn = p.N / BN;
     const int ntm = (p.M + BM - 1) / BM;
     constexpr int lds = 2 * (BM + BN) * 128;
-    static bool once = false;
-    if (!once) { set_max_lds(gemm_kernel<T, BM, BN, EPI>, lds); once = true; }
     dim3 grid(ntm * p.ntn, 1, split);
     hipLaunchKernelGGL((gemm_kernel<T, BM, BN, EPI>), grid, dim3(256), lds, e->stream, p);
     HIPCHECK(hipGetLastError());
@@ -223,15 +224,11 @@ void enc_attention(mocr_engine* e, const void* qkv, void* ctx, int n, int impl) 
     if (impl == 1 && sizeof(T) == 2) {
         ProfScope ps(e, "enc_attn_mfma", flops, bytes);
         constexpr int lds = ENC_SP * 128 + 64 * ENC_VT_LD * 2;
-        static bool once = false;
-        if (!once) { set_max_lds(enc_attn_mfma_kernel, lds); once = true; }
         hipLaunchKernelGGL(enc_attn_mfma_kernel, dim3(n * H), dim3(256), lds, e->stream,
                            reinterpret_cast<const bf16_t*>(qkv), reinterpret_cast<bf16_t*>(ctx), H, 3 * e->D, e->D);
     } else {
         ProfScope ps(e, "enc_attn_simple", flops, bytes);
         constexpr int lds = (200 * 65 + 200 * 64 + 4 * 64 + 4 * 256) * 4;
-        static bool once = false;
-        if (!once) { set_max_lds(enc_attn_simple_kernel<T>, lds); once = true; }
         hipLaunchKernelGGL((enc_attn_simple_kernel<T>), dim3(n * H), dim3(256), lds, e->stream,
                            reinterpret_cast<const T*>(qkv), reinterpret_cast<T*>(ctx), S, H, 3 * e->D, e->D, 0.125f);
     }
@@ -298,10 +295,10 @@ void dec_add_ln(mocr_engine* e, int nslab, int N, const float* bias, const float
                 float* out_f32, void* out_t, int rows, bool gelu) {
     ProfScope ps(e, "dec_add_ln", 0, (double)rows * N * 4 * (nslab + 3));
     if (gelu)
-        hipLaunchKernelGGL((dec_add_ln_kernel<T, 768, true>), dim3((rows + 3) / 4), dim3(256), 0, e->stream, e->slabs, nslab,
+        hipLaunchKernelGGL((dec_add_ln_kernel<T, 768, true>), dim3(rows), dim3(192), 0, e->stream, e->slabs, nslab,
                            (long long)e->Bp * N, bias, resid, g, b, out_f32, reinterpret_cast<T*>(out_t), rows, e->cfg.ln_eps);
     else
-        hipLaunchKernelGGL((dec_add_ln_kernel<T, 768, false>), dim3((rows + 3) / 4), dim3(256), 0, e->stream, e->slabs, nslab,
+        hipLaunchKernelGGL((dec_add_ln_kernel<T, 768, false>), dim3(rows), dim3(192), 0, e->stream, e->slabs, nslab,
                            (long long)e->Bp * N, bias, resid, g, b, out_f32, reinterpret_cast<T*>(out_t), rows, e->cfg.ln_eps);
     HIPCHECK(hipGetLastError());
 }
@@ -352,7 +349,8 @@ void dec_attn(mocr_engine* e, int layer, int nslab, int n, const float* bias, in
     p.ctx = e->ctx_t; p.H = H; p.scale = 0.125f;
     ProfScope ps(e, SELF ? "dec_attn_self" : "dec_attn_cross", 4.0 * n * H * approx_len * 64,
                  2.0 * n * H * approx_len * 64 * sizeof(T));
-    hipLaunchKernelGGL((dec_attn_kernel<T, SELF>), dim3(n * (H / 4)), dim3(256), 0, e->stream, p);
+    if (e->cfg.max_len > 320) throw ArgError{"max_len > 320 needs a larger NG", MOCR_ERR_UNSUPPORTED};
+    hipLaunchKernelGGL((dec_attn_kernel<T, SELF, (SELF ? 10 : 7)>), dim3(n * H), dim3(256), 0, e->stream, p);
     HIPCHECK(hipGetLastError());
 }
 
@@ -396,6 +394,49 @@ void run_cross_kv(mocr_engine* e, int n) {
             EPI_BIAS, 128, 1);
 }
 
+// Raise the dynamic-LDS limit of every kernel that needs it (done once, outside any capture).
+template <typename T> void init_kernel_attrs() {
+    constexpr int l128 = 2 * (128 + 128) * 128, l64 = 2 * (64 + 64) * 128;
+    set_max_lds(gemm_kernel<T, 128, 128, EPI_SLAB>, l128);
+    set_max_lds(gemm_kernel<T, 128, 128, EPI_BIAS>, l128);
+    set_max_lds(gemm_kernel<T, 128, 128, EPI_BIAS_GELU>, l128);
+    set_max_lds(gemm_kernel<T, 128, 128, EPI_BIAS_RESID>, l128);
+    set_max_lds(gemm_kernel<T, 128, 128, EPI_PATCH>, l128);
+    set_max_lds(gemm_kernel<T, 128, 128, EPI_BIAS_F32>, l128);
+    set_max_lds(gemm_kernel<T, 64, 64, EPI_SLAB>, l64);
+    set_max_lds(gemm_kernel<T, 64, 64, EPI_BIAS>, l64);
+    set_max_lds(gemm_kernel<T, 64, 64, EPI_BIAS_GELU>, l64);
+    set_max_lds(gemm_kernel<T, 64, 64, EPI_BIAS_RESID>, l64);
+    set_max_lds(gemm_kernel<T, 64, 64, EPI_PATCH>, l64);
+    set_max_lds(gemm_kernel<T, 64, 64, EPI_BIAS_F32>, l64);
+    set_max_lds(enc_attn_simple_kernel<T>, (200 * 65 + 200 * 64 + 4 * 64 + 4 * 256) * 4);
+    set_max_lds(enc_attn_mfma_kernel, ENC_SP * 128 + 64 * ENC_VT_LD * 2);
+}
+
+// `steps` consecutive greedy steps captured once and replayed: every per-step value (position,
+// token, finished flags) lives in device memory, so the launch sequence is identical each step.
+template <typename T>
+hipGraphExec_t decode_graph(mocr_engine* e, const DecState& st, int n, int steps) {
+    const auto key = std::make_tuple(n, st.max_len, steps);
+    auto it = e->graphs.find(key);
+    if (it != e->graphs.end()) return it->second;
+    hipGraph_t g = nullptr;
+    HIPCHECK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+    try {
+        for (int i = 0; i < steps; ++i) decode_step<T>(e, st, n, 0);
+    } catch (...) {
+        (void)hipStreamEndCapture(e->stream, &g);
+        if (g) (void)hipGraphDestroy(g);
+        throw;
+    }
+    HIPCHECK(hipStreamEndCapture(e->stream, &g));
+    hipGraphExec_t ge = nullptr;
+    HIPCHECK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    HIPCHECK(hipGraphDestroy(g));
+    e->graphs[key] = ge;
+    return ge;
+}
+
 // Greedy loop.  Returns the number of steps launched.
 template <typename T>
 int run_decode(mocr_engine* e, int n, int max_len, const int* forced, int forced_T, float* logits_out, bool allow_sync) {
@@ -403,13 +444,22 @@ int run_decode(mocr_engine* e, int n, int max_len, const int* forced, int forced
     dec_token<T, true>(e, st, 0, n);
     const int steps = forced ? forced_T : max_len - 1;
     const bool early = allow_sync && !forced && !(e->cfg.flags & MOCR_FLAG_NO_EARLY_EXIT);
+    const bool use_graph = !forced && !e->prof_on && !(e->cfg.flags & MOCR_FLAG_NO_GRAPH);
+    constexpr int CH = 8;
     int t = 0;
-    for (; t < steps; ++t) {
-        decode_step<T>(e, st, n, t);
-        if (early && (t % 16) == 15 && t + 1 < steps) {
+    while (t < steps) {
+        if (use_graph) {
+            const int k = (steps - t >= CH) ? CH : 1;
+            HIPCHECK(hipGraphLaunch(decode_graph<T>(e, st, n, k), e->stream));
+            t += k;
+        } else {
+            decode_step<T>(e, st, n, t);
+            ++t;
+        }
+        if (early && (t % 16) == 0 && t < steps) {
             HIPCHECK(hipMemcpyAsync(e->h_pinned, e->n_unf, sizeof(int), hipMemcpyDeviceToHost, e->stream));
             HIPCHECK(hipStreamSynchronize(e->stream));
-            if (*e->h_pinned <= 0) { ++t; break; }
+            if (*e->h_pinned <= 0) break;
         }
     }
     return t;
@@ -559,6 +609,7 @@ void commit_weights(mocr_engine* e) {
     w.lntb = up.f32(up.get(cl + "transform.LayerNorm.bias", {D}));
     w.wv = up.mat(up.get(cl + "decoder.weight", {V, D}));
     w.bv = up.f32(up.get(cl + "decoder.bias", {V}));
+    if (c.dtype == MOCR_BF16) init_kernel_attrs<bf16_t>(); else init_kernel_attrs<float>();
     e->host_w.clear();
     e->host_shape.clear();
     e->committed = true;
@@ -640,7 +691,7 @@ int mocr_abi_version(void) { return MOCR_ABI_VERSION; }
 int mocr_create(const mocr_config* cfg, mocr_engine** out) {
     if (!cfg || !out || cfg->struct_size != (int32_t)sizeof(mocr_config)) return MOCR_ERR_ARG;
     if (cfg->hidden != 768 || cfg->heads != 12 || cfg->image_size != 224 || cfg->patch_size != 16 || cfg->ffn % 128 ||
-        cfg->vocab % 1024 || cfg->max_len < 2 || cfg->max_len > 320 || cfg->max_len > cfg->max_pos || cfg->max_batch < 1 ||
+        cfg->vocab != 6144 || cfg->max_len < 2 || cfg->max_len > 320 || cfg->max_len > cfg->max_pos || cfg->max_batch < 1 ||
         (cfg->dtype != MOCR_F32 && cfg->dtype != MOCR_BF16) || cfg->enc_layers < 1 || cfg->dec_layers < 1)
         return MOCR_ERR_UNSUPPORTED;
     mocr_engine* e = new (std::nothrow) mocr_engine();
@@ -669,6 +720,7 @@ void mocr_destroy(mocr_engine* e) {
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (auto& r : e->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
+    for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
     for (void* p : e->allocs) (void)hipFree(p);
     if (e->h_pinned) (void)hipHostFree(e->h_pinned);
     if (e->stream) (void)hipStreamDestroy(e->stream);

@@ -232,78 +232,135 @@ struct DecAttnParams {
     float scale;
 };
 
-template <typename T, bool SELF>
+// raw 8-element row chunk: 16 B in bf16, 32 B in fp32; loads issue without being consumed
+template <typename T> struct raw8;
+template <> struct raw8<bf16_t> {
+    uint4 v;
+    __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const uint4*>(p); }
+    __device__ __forceinline__ void unpack(float* o) const {
+        o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+        o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+        o[4] = __uint_as_float(v.z << 16); o[5] = __uint_as_float(v.z & 0xffff0000u);
+        o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xffff0000u);
+    }
+};
+template <> struct raw8<float> {
+    float4 a, b;
+    __device__ __forceinline__ void load(const float* p) {
+        a = *reinterpret_cast<const float4*>(p); b = *reinterpret_cast<const float4*>(p + 4);
+    }
+    __device__ __forceinline__ void unpack(float* o) const {
+        o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+    }
+};
+
+// sum over lane groups g (lanes 8g+c share c): every lane ends with the total
+__device__ __forceinline__ float group_sum(float v) {
+    v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+// One block per (sequence, head); the keys are split over the block's 4 waves, and a wave issues
+// EVERY K and V row load of its share (NG groups of 8 rows) before consuming any: one memory round
+// trip per step instead of one per 8 rows.  The partial softmaxes are merged through LDS
+// (running-max form).  The split-K slabs of the query projection are summed with slab s on lane
+// group s mod 8, so that sum is one round trip as well.
+template <typename T, bool SELF, int NG>
 __global__ __launch_bounds__(256) void dec_attn_kernel(DecAttnParams p) {
-    constexpr int DH = 64, LMAX = 320;
-    __shared__ float s_sc[4][LMAX];
+    constexpr int DH = 64;
+    __shared__ float s_m[4], s_l[4];
+    __shared__ float s_acc[4][DH];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g = lane >> 3, c = lane & 7;
-    const int hpb = p.H / 4;
-    const int b = blockIdx.x / hpb;
-    const int h = (blockIdx.x % hpb) * 4 + wave;
+    const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
     const int D = p.H * DH;
     const int col = h * DH + c * 8;
-    float* sc = s_sc[wave];
 
-    float q[8], kn[8], vn[8];
-    {
-        float4 a0 = *reinterpret_cast<const float4*>(p.bias + col), a1 = *reinterpret_cast<const float4*>(p.bias + col + 4);
-        q[0] = a0.x; q[1] = a0.y; q[2] = a0.z; q[3] = a0.w; q[4] = a1.x; q[5] = a1.y; q[6] = a1.z; q[7] = a1.w;
-        if (SELF) {
-            a0 = *reinterpret_cast<const float4*>(p.bias + D + col); a1 = *reinterpret_cast<const float4*>(p.bias + D + col + 4);
-            kn[0] = a0.x; kn[1] = a0.y; kn[2] = a0.z; kn[3] = a0.w; kn[4] = a1.x; kn[5] = a1.y; kn[6] = a1.z; kn[7] = a1.w;
-            a0 = *reinterpret_cast<const float4*>(p.bias + 2 * D + col); a1 = *reinterpret_cast<const float4*>(p.bias + 2 * D + col + 4);
-            vn[0] = a0.x; vn[1] = a0.y; vn[2] = a0.z; vn[3] = a0.w; vn[4] = a1.x; vn[5] = a1.y; vn[6] = a1.z; vn[7] = a1.w;
+    const int L = SELF ? p.step[b] + 1 : p.cross_len;
+    const int Lc = SELF ? L - 1 : L;                       // keys that live in memory
+    int per = (Lc + 3) >> 2;
+    per = (per + 7) & ~7;
+    const int k_begin = wave * per;
+    const int k_end = min(Lc, k_begin + per);
+    const T* kb = reinterpret_cast<const T*>(p.kbase) + (size_t)b * p.kv_batch_stride + (size_t)h * p.kv_head_stride + c * 8;
+    const T* vb = reinterpret_cast<const T*>(p.vbase) + (size_t)b * p.kv_batch_stride + (size_t)h * p.kv_head_stride + c * 8;
+
+    // ---- issue every K/V load of this wave (clamped rows are valid addresses and get weight 0)
+    raw8<T> kr[NG], vr[NG];
+    const int last = Lc > 0 ? Lc - 1 : 0;
+    if (Lc > 0) {
+#pragma unroll
+        for (int u = 0; u < NG; ++u) {
+            const int key = min(k_begin + 8 * u + g, last);
+            kr[u].load(kb + (size_t)key * p.kv_row_stride);
         }
-        for (int s = 0; s < p.nslab; ++s) {
-            const float* r = p.slabs + (size_t)s * p.slab_stride + (size_t)b * p.ldq + col;
-            float4 x0 = *reinterpret_cast<const float4*>(r), x1 = *reinterpret_cast<const float4*>(r + 4);
-            q[0] += x0.x; q[1] += x0.y; q[2] += x0.z; q[3] += x0.w; q[4] += x1.x; q[5] += x1.y; q[6] += x1.z; q[7] += x1.w;
-            if (SELF) {
-                x0 = *reinterpret_cast<const float4*>(r + D); x1 = *reinterpret_cast<const float4*>(r + D + 4);
-                kn[0] += x0.x; kn[1] += x0.y; kn[2] += x0.z; kn[3] += x0.w; kn[4] += x1.x; kn[5] += x1.y; kn[6] += x1.z; kn[7] += x1.w;
-                x0 = *reinterpret_cast<const float4*>(r + 2 * D); x1 = *reinterpret_cast<const float4*>(r + 2 * D + 4);
-                vn[0] += x0.x; vn[1] += x0.y; vn[2] += x0.z; vn[3] += x0.w; vn[4] += x1.x; vn[5] += x1.y; vn[6] += x1.z; vn[7] += x1.w;
+#pragma unroll
+        for (int u = 0; u < NG; ++u) {
+            const int key = min(k_begin + 8 * u + g, last);
+            vr[u].load(vb + (size_t)key * p.kv_row_stride);
+        }
+    }
+    // ---- query (and for SELF the new key/value) = sum of split-K slabs + bias
+    float q[8], kn[8], vn[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { q[e] = 0.f; kn[e] = 0.f; vn[e] = 0.f; }
+    for (int s = g; s < p.nslab; s += 8) {
+        const float* r = p.slabs + (size_t)s * p.slab_stride + (size_t)b * p.ldq + col;
+        const float4 x0 = *reinterpret_cast<const float4*>(r), x1 = *reinterpret_cast<const float4*>(r + 4);
+        q[0] += x0.x; q[1] += x0.y; q[2] += x0.z; q[3] += x0.w; q[4] += x1.x; q[5] += x1.y; q[6] += x1.z; q[7] += x1.w;
+        if (SELF) {
+            const float4 y0 = *reinterpret_cast<const float4*>(r + D), y1 = *reinterpret_cast<const float4*>(r + D + 4);
+            const float4 z0 = *reinterpret_cast<const float4*>(r + 2 * D), z1 = *reinterpret_cast<const float4*>(r + 2 * D + 4);
+            kn[0] += y0.x; kn[1] += y0.y; kn[2] += y0.z; kn[3] += y0.w; kn[4] += y1.x; kn[5] += y1.y; kn[6] += y1.z; kn[7] += y1.w;
+            vn[0] += z0.x; vn[1] += z0.y; vn[2] += z0.z; vn[3] += z0.w; vn[4] += z1.x; vn[5] += z1.y; vn[6] += z1.z; vn[7] += z1.w;
+        }
+    }
+    {
+        const float4 a0 = *reinterpret_cast<const float4*>(p.bias + col), a1 = *reinterpret_cast<const float4*>(p.bias + col + 4);
+        const float bq[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) q[e] = group_sum(q[e]) + bq[e];
+        if (SELF) {
+            const float4 c0 = *reinterpret_cast<const float4*>(p.bias + D + col), c1 = *reinterpret_cast<const float4*>(p.bias + D + col + 4);
+            const float4 d0 = *reinterpret_cast<const float4*>(p.bias + 2 * D + col), d1 = *reinterpret_cast<const float4*>(p.bias + 2 * D + col + 4);
+            const float bk[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+            const float bv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { kn[e] = group_sum(kn[e]) + bk[e]; vn[e] = group_sum(vn[e]) + bv[e]; }
+            if (sizeof(T) == 2) {   // the cache holds bf16: attend to exactly the values it stores
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { kn[e] = bf2f(f2bf(kn[e])); vn[e] = bf2f(f2bf(vn[e])); }
+            }
+            if (wave == 0 && g == 0) {
+                elem<T>::st8(const_cast<T*>(kb) + (size_t)(L - 1) * p.kv_row_stride, kn);
+                elem<T>::st8(const_cast<T*>(vb) + (size_t)(L - 1) * p.kv_row_stride, vn);
             }
         }
     }
-    const int L = SELF ? p.step[b] + 1 : p.cross_len;
-    const int Lc = SELF ? L - 1 : L;                    // keys read from memory
-    const T* kb = reinterpret_cast<const T*>(p.kbase) + (size_t)b * p.kv_batch_stride + (size_t)h * p.kv_head_stride + c * 8;
-    const T* vb = reinterpret_cast<const T*>(p.vbase) + (size_t)b * p.kv_batch_stride + (size_t)h * p.kv_head_stride + c * 8;
-    if (SELF) {
-        // the cache stores what the storage dtype can hold; attend to exactly those values
-        T* kw = const_cast<T*>(kb) + (size_t)(L - 1) * p.kv_row_stride;
-        T* vw = const_cast<T*>(vb) + (size_t)(L - 1) * p.kv_row_stride;
-        if (sizeof(T) == 2) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { kn[e] = bf2f(f2bf(kn[e])); vn[e] = bf2f(f2bf(vn[e])); }
-        }
-        if (g == 0) { elem<T>::st8(kw, kn); elem<T>::st8(vw, vn); }
-    }
-    // ---- pass 1: scores
+    // ---- scores of this wave's keys
+    float sc[NG];
     float mx = -INFINITY;
-#pragma unroll 4
-    for (int k0 = 0; k0 < Lc; k0 += 8) {
-        const int key = k0 + g;
-        float part = 0.f;
-        if (key < Lc) {
+    if (Lc > 0) {
+#pragma unroll
+        for (int u = 0; u < NG; ++u) {
             float kv[8];
-            elem<T>::ld8(kb + (size_t)key * p.kv_row_stride, kv);
+            kr[u].unpack(kv);
+            float part = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) part += q[e] * kv[e];
+            part += __shfl_xor(part, 1, 64);
+            part += __shfl_xor(part, 2, 64);
+            part += __shfl_xor(part, 4, 64);
+            const bool valid = (k_begin + 8 * u + g) < k_end;
+            sc[u] = valid ? part * p.scale : -INFINITY;
+            mx = fmaxf(mx, sc[u]);
         }
-        part += __shfl_xor(part, 1, 64);
-        part += __shfl_xor(part, 2, 64);
-        part += __shfl_xor(part, 4, 64);
-        part *= p.scale;
-        if (key < Lc) {
-            if (c == 0) sc[key] = part;
-            mx = fmaxf(mx, part);
-        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < NG; ++u) sc[u] = -INFINITY;
     }
-    float s_new = 0.f;
-    if (SELF) {
+    float s_new = -INFINITY;
+    if (SELF && wave == 0) {
         float part = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) part += q[e] * kn[e];
@@ -313,40 +370,49 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(DecAttnParams p) {
         s_new = part * p.scale;
         mx = fmaxf(mx, s_new);
     }
-    mx = wave_max(mx);
-    __syncthreads();
-    // ---- pass 2: exponentials (lane owns keys lane, lane+64, ...)
-    float sum = 0.f;
-    for (int key = lane; key < Lc; key += 64) {
-        const float e = expf(sc[key] - mx);
-        sc[key] = e;
-        sum += e;
-    }
-    sum = wave_sum(sum);
-    float p_new = 0.f;
-    if (SELF) { p_new = expf(s_new - mx); sum += p_new; }
-    __syncthreads();
-    // ---- pass 3: weighted values
+    mx = fmaxf(mx, __shfl_xor(mx, 8, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    // ---- partial softmax numerator / denominator of this wave
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int k0 = 0; k0 < Lc; k0 += 8) {
-        const int key = k0 + g;
-        if (key < Lc) {
-            float vv[8];
-            elem<T>::ld8(vb + (size_t)key * p.kv_row_stride, vv);
-            const float pk = sc[key];
+    float lsum = 0.f;
+    if (mx > -INFINITY) {
+        if (Lc > 0) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] += pk * vv[e];
+            for (int u = 0; u < NG; ++u) {
+                const float pk = expf(sc[u] - mx);        // exp(-inf) = 0 for clamped rows
+                float vv[8];
+                vr[u].unpack(vv);
+                lsum += pk;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += pk * vv[e];
+            }
+        }
+        lsum = group_sum(lsum);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = group_sum(acc[e]);
+        if (SELF && wave == 0) {
+            const float pn = expf(s_new - mx);
+            lsum += pn;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += pn * vn[e];
         }
     }
+    if (g == 0) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        float a = acc[e];
-        a += __shfl_xor(a, 8, 64);
-        a += __shfl_xor(a, 16, 64);
-        a += __shfl_xor(a, 32, 64);
-        if (SELF) a += p_new * vn[e];
-        acc[e] = a / sum;
+        for (int e = 0; e < 8; ++e) s_acc[wave][c * 8 + e] = acc[e];
+        if (c == 0) { s_m[wave] = mx; s_l[wave] = lsum; }
     }
-    if (g == 0) elem<T>::st8(reinterpret_cast<T*>(p.ctx) + (size_t)b * D + col, acc);
+    __syncthreads();
+    if (wave == 0) {
+        const float m = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+        float num = 0.f, den = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float f = expf(s_m[w] - m);             // 0 for a wave without keys
+            num += f * s_acc[w][lane];
+            den += f * s_l[w];
+        }
+        elem<T>::st(reinterpret_cast<T*>(p.ctx) + (size_t)b * D + h * DH + lane, num / den);
+    }
 }

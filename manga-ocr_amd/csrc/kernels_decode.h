@@ -7,50 +7,63 @@
 #include "common.h"
 
 // out = LayerNorm( [gelu]( sum_s slab_s + bias ) [+ resid] ) ; writes fp32 (next residual) and T
-// (next GEMM operand).  One wave per row of 768.
+// (next GEMM operand).  One block of D/4 threads per row, one float4 per thread; the slab loads
+// are issued four at a time (independent accumulators) so the row costs ~nslab/4 memory round
+// trips instead of nslab.
 template <typename T, int D, bool GELU>
-__global__ __launch_bounds__(256) void dec_add_ln_kernel(const float* __restrict__ slabs, int nslab, long long slab_stride,
-                                                         const float* __restrict__ bias, const float* __restrict__ resid,
-                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         float* __restrict__ out_f32, T* __restrict__ out_t, int rows, float eps) {
-    constexpr int V = D / 256;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (row >= rows) return;
-    float v[V * 4];
+__global__ __launch_bounds__(D / 4) void dec_add_ln_kernel(const float* __restrict__ slabs, int nslab, long long slab_stride,
+                                                           const float* __restrict__ bias, const float* __restrict__ resid,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ out_f32, T* __restrict__ out_t, int rows, float eps) {
+    constexpr int NW = D / 256;                      // waves per block
+    __shared__ float s_red[2][NW];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = tid * 4;
+    const float* sp = slabs + (size_t)row * D + c;
+    const float4 bv = *reinterpret_cast<const float4*>(bias + c);
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (resid) r = *reinterpret_cast<const float4*>(resid + (size_t)row * D + c);
+    // eight slab loads in flight at a time; indices past nslab are clamped (a valid, cached
+    // address) and weighted 0 - a per-load branch would serialise the loads
+    float v[4] = {bv.x, bv.y, bv.z, bv.w};
+    for (int s0 = 0; s0 < nslab; s0 += 8) {
+        float4 x[8];
 #pragma unroll
-    for (int i = 0; i < V; ++i) {
-        const int c = i * 256 + lane * 4;
-        float4 a = *reinterpret_cast<const float4*>(bias + c);
-        for (int s = 0; s < nslab; ++s) {
-            const float4 x = *reinterpret_cast<const float4*>(slabs + (size_t)s * slab_stride + (size_t)row * D + c);
-            a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
+        for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const float4*>(sp + (size_t)min(s0 + u, nslab - 1) * slab_stride);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float w = (s0 + u < nslab) ? 1.f : 0.f;
+            v[0] += w * x[u].x; v[1] += w * x[u].y; v[2] += w * x[u].z; v[3] += w * x[u].w;
         }
-        if (GELU) { a.x = gelu_erf(a.x); a.y = gelu_erf(a.y); a.z = gelu_erf(a.z); a.w = gelu_erf(a.w); }
-        if (resid) {
-            const float4 r = *reinterpret_cast<const float4*>(resid + (size_t)row * D + c);
-            a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w;
-        }
-        v[4 * i] = a.x; v[4 * i + 1] = a.y; v[4 * i + 2] = a.z; v[4 * i + 3] = a.w;
     }
-    float s = 0.f;
+    if (GELU) {
 #pragma unroll
-    for (int i = 0; i < V * 4; ++i) s += v[i];
-    const float mean = wave_sum(s) * (1.0f / D);
+        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+    }
+    v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+    float sm = wave_sum((v[0] + v[1]) + (v[2] + v[3]));
+    if (lane == 0) s_red[0][wave] = sm;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) tot += s_red[0][w];
+    const float mean = tot * (1.0f / D);
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < V * 4; ++i) { const float d = v[i] - mean; q += d * d; }
-    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / D) + eps);
+    for (int e = 0; e < 4; ++e) { const float d = v[e] - mean; q += d * d; }
+    q = wave_sum(q);
+    if (lane == 0) s_red[1][wave] = q;
+    __syncthreads();
+    tot = 0.f;
 #pragma unroll
-    for (int i = 0; i < V; ++i) {
-        const int c = i * 256 + lane * 4;
-        const float4 g = *reinterpret_cast<const float4*>(gamma + c);
-        const float4 b = *reinterpret_cast<const float4*>(beta + c);
-        float o[4] = {(v[4 * i] - mean) * rstd * g.x + b.x, (v[4 * i + 1] - mean) * rstd * g.y + b.y,
-                      (v[4 * i + 2] - mean) * rstd * g.z + b.z, (v[4 * i + 3] - mean) * rstd * g.w + b.w};
-        if (out_f32) *reinterpret_cast<float4*>(out_f32 + (size_t)row * D + c) = make_float4(o[0], o[1], o[2], o[3]);
-        elem<T>::st4(out_t + (size_t)row * D + c, o);
-    }
+    for (int w = 0; w < NW; ++w) tot += s_red[1][w];
+    const float rstd = 1.0f / sqrtf(tot * (1.0f / D) + eps);
+    const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+    const float4 b = *reinterpret_cast<const float4*>(beta + c);
+    float o[4] = {(v[0] - mean) * rstd * g.x + b.x, (v[1] - mean) * rstd * g.y + b.y, (v[2] - mean) * rstd * g.z + b.z,
+                  (v[3] - mean) * rstd * g.w + b.w};
+    if (out_f32) *reinterpret_cast<float4*>(out_f32 + (size_t)row * D + c) = make_float4(o[0], o[1], o[2], o[3]);
+    elem<T>::st4(out_t + (size_t)row * D + c, o);
 }
 
 // out T = gelu( sum_s slab_s + bias )   (the decoder FFN's intermediate activation)
@@ -60,12 +73,20 @@ __global__ void dec_bias_gelu_kernel(const float* __restrict__ slabs, int nslab,
     const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i >= (long long)rows * N) return;
     const int c = (int)(i % N);
-    float4 a = *reinterpret_cast<const float4*>(bias + c);
-    for (int s = 0; s < nslab; ++s) {
-        const float4 x = *reinterpret_cast<const float4*>(slabs + (size_t)s * slab_stride + i);
-        a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
+    float4 a0 = *reinterpret_cast<const float4*>(bias + c);
+    float4 a1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    int s = 0;
+    for (; s + 2 <= nslab; s += 2) {
+        const float4 x0 = *reinterpret_cast<const float4*>(slabs + (size_t)s * slab_stride + i);
+        const float4 x1 = *reinterpret_cast<const float4*>(slabs + (size_t)(s + 1) * slab_stride + i);
+        a0.x += x0.x; a0.y += x0.y; a0.z += x0.z; a0.w += x0.w;
+        a1.x += x1.x; a1.y += x1.y; a1.z += x1.z; a1.w += x1.w;
     }
-    float o[4] = {gelu_erf(a.x), gelu_erf(a.y), gelu_erf(a.z), gelu_erf(a.w)};
+    if (s < nslab) {
+        const float4 x0 = *reinterpret_cast<const float4*>(slabs + (size_t)s * slab_stride + i);
+        a0.x += x0.x; a0.y += x0.y; a0.z += x0.z; a0.w += x0.w;
+    }
+    float o[4] = {gelu_erf(a0.x + a1.x), gelu_erf(a0.y + a1.y), gelu_erf(a0.z + a1.z), gelu_erf(a0.w + a1.w)};
     elem<T>::st4(out + i, o);
 }
 
@@ -114,18 +135,27 @@ __global__ __launch_bounds__(256) void dec_token_kernel(const float* __restrict_
         const int t = st.step[b];
         float best = -INFINITY;
         int bi = 0x7fffffff;
-        for (int c = tid * 4; c < V; c += 1024) {
-            float4 a = *reinterpret_cast<const float4*>(vbias + c);
-            for (int s = 0; s < nslab; ++s) {
-                const float4 x = *reinterpret_cast<const float4*>(slabs + (size_t)s * slab_stride + (size_t)b * V + c);
-                a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
+        constexpr int NC = 6;                            // vocab = NC * 1024 columns (6144)
+        float4 a[NC];
+#pragma unroll
+        for (int j = 0; j < NC; ++j) a[j] = *reinterpret_cast<const float4*>(vbias + tid * 4 + j * 1024);
+        for (int s = 0; s < nslab; ++s) {
+            const float* sp = slabs + (size_t)s * slab_stride + (size_t)b * V + tid * 4;
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                const float4 x = *reinterpret_cast<const float4*>(sp + j * 1024);
+                a[j].x += x.x; a[j].y += x.y; a[j].z += x.z; a[j].w += x.w;
             }
+        }
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            const int c = tid * 4 + j * 1024;
             if (st.logits_out)
-                *reinterpret_cast<float4*>(st.logits_out + ((size_t)b * st.forced_T + t) * V + c) = a;
-            if (a.x > best) { best = a.x; bi = c; }
-            if (a.y > best) { best = a.y; bi = c + 1; }
-            if (a.z > best) { best = a.z; bi = c + 2; }
-            if (a.w > best) { best = a.w; bi = c + 3; }
+                *reinterpret_cast<float4*>(st.logits_out + ((size_t)b * st.forced_T + t) * V + c) = a[j];
+            if (a[j].x > best) { best = a[j].x; bi = c; }
+            if (a[j].y > best) { best = a[j].y; bi = c + 1; }
+            if (a[j].z > best) { best = a[j].z; bi = c + 2; }
+            if (a[j].w > best) { best = a[j].w; bi = c + 3; }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
