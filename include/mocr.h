@@ -74,6 +74,7 @@ typedef struct mocr_config {
     int32_t pad_id;      /* 0 */
     float ln_eps;        /* 1e-12 */
     int32_t flags;
+    int32_t lanes;       /* batches kept in flight on separate HIP streams (0 = 1); each has its own workspace */
 } mocr_config;
 
 int mocr_abi_version(void);
@@ -100,13 +101,15 @@ int mocr_recognize(mocr_engine* e, const uint8_t* images, int32_t n, int32_t h, 
                    int64_t row_stride, int64_t image_stride, int32_t channels,
                    int32_t* out_ids, int32_t* out_len);
 
-/* THE HOT PATH (device buffers, asynchronous): d_gray is a device pointer to n contiguous
- * image_size x image_size uint8 luminance planes, d_out_ids / d_out_len device pointers
- * ([n,max_len] / [n] int32), n <= max_batch.  Work is enqueued on the engine's stream
- * (mocr_stream()); call mocr_synchronize() before reading the outputs. */
+/* THE HOT PATH (device buffers, asynchronous): submits one batch.  d_gray is a device pointer to
+ * n contiguous image_size x image_size uint8 luminance planes, d_out_ids / d_out_len device
+ * pointers ([n,max_len] / [n] int32), n <= max_batch; all three must stay valid until
+ * mocr_synchronize() returns.  Batches submitted back to back run concurrently on the engine's
+ * lanes; mocr_synchronize() schedules every submitted batch to completion (greedy steps in
+ * chunks, stopping a batch once all of its rows have emitted EOS) and waits for the GPU. */
 int mocr_recognize_device(mocr_engine* e, const void* d_gray, int32_t n, void* d_out_ids, void* d_out_len);
 int mocr_synchronize(mocr_engine* e);
-/* The hipStream_t the engine launches on (so a caller can order its own work / events). */
+/* The hipStream_t of lane 0 (the stream the test hooks and single-lane engines launch on). */
 void* mocr_stream(mocr_engine* e);
 
 /* ---- test hooks (fp32 out; used by tests/ and __graft_entry__.smoke()) -------------------- */

@@ -72,20 +72,15 @@ struct ProfRec { int kid; hipEvent_t e0, e1; double flops, bytes; };
 
 }  // namespace
 
-struct mocr_engine {
-    mocr_config cfg{};
-    std::string err;
-    std::mutex mu;
+// Everything one in-flight batch needs: a HIP stream and its own workspace.  The engine keeps
+// `lanes` of them (the counterpart of the reference's pool of QueueProcessorWorker threads,
+// src/ui/main_window.py:4286-4327): independent batches overlap on the GPU, which is what fills
+// the chip during the latency-bound decode steps.  Host code runs single-threaded under the
+// engine mutex and "binds" one lane at a time: mocr_engine derives from LaneCtx, and bind()
+// copies the lane's pointers into that base, so the launch code simply says e->X, e->stream.
+struct LaneCtx {
+    int lane_id = 0;
     hipStream_t stream = nullptr;
-    bool committed = false;
-    std::map<std::string, std::vector<float>> host_w;
-    std::map<std::string, std::vector<int64_t>> host_shape;
-    std::vector<void*> allocs;
-    Weights w;
-    // geometry
-    int S = 0, G = 0, D = 0, H = 0, F = 0, V = 0, Bp = 0, Mp = 0, NCKV = 0;
-    size_t esz = 2;
-    // workspace
     uint8_t *d_in = nullptr, *d_rgb = nullptr;
     float* X = nullptr;
     void *Xn = nullptr, *QKV = nullptr, *CTX = nullptr, *Hb = nullptr, *ENC = nullptr, *CKV = nullptr;
@@ -95,9 +90,48 @@ struct mocr_engine {
     void *x_t = nullptr, *a_t = nullptr, *c_t = nullptr, *ctx_t = nullptr, *h_t = nullptr, *z_t = nullptr;
     int *ids = nullptr, *step = nullptr, *finished = nullptr, *len = nullptr, *n_unf = nullptr;
     int* forced = nullptr; float* logits_dbg = nullptr; size_t forced_cap = 0, logits_cap = 0;
-    int* h_pinned = nullptr;
-    // decode-step HIP graphs, keyed by (rows, max_len, steps per graph)
-    std::map<std::tuple<int, int, int>, hipGraphExec_t> graphs;
+    int* h_pinned = nullptr;                        // [4] pinned: early-exit flags
+};
+
+// One recognise request of <= max_batch crops.
+struct Job {
+    const uint8_t* src = nullptr;   // host images (src_host) or device luminance planes
+    bool src_host = false;
+    int channels = 1;
+    int64_t row_stride = 0, image_stride = 0;
+    int n = 0, max_len = 0;
+    int32_t* out_ids = nullptr;     // host (out_host) or device
+    int32_t* out_len = nullptr;
+    bool out_host = false;
+};
+
+struct Lane {
+    LaneCtx ctx;
+    bool active = false;
+    Job job;
+    int t = 0, steps = 0, chunk = 0;
+    bool flag_pending[2] = {false, false};
+    hipEvent_t flag_ev[2] = {nullptr, nullptr};
+};
+
+struct mocr_engine : LaneCtx {
+    mocr_config cfg{};
+    std::string err;
+    std::mutex mu;
+    bool committed = false;
+    std::map<std::string, std::vector<float>> host_w;
+    std::map<std::string, std::vector<int64_t>> host_shape;
+    std::vector<void*> allocs;
+    Weights w;
+    // geometry
+    int S = 0, G = 0, D = 0, H = 0, F = 0, V = 0, Bp = 0, Mp = 0, NCKV = 0;
+    size_t esz = 2;
+    std::vector<Lane> lanes;
+    std::vector<Job> pending;
+    // decode-step HIP graphs, keyed by (lane, rows, max_len, steps per graph)
+    std::map<std::tuple<int, int, int, int>, hipGraphExec_t> graphs;
+    void bind(int i) { static_cast<LaneCtx&>(*this) = lanes[i].ctx; }
+    void unbind(int i) { lanes[i].ctx = static_cast<LaneCtx&>(*this); }
     // profiling
     bool prof_on = false;
     std::vector<std::string> knames;
@@ -137,7 +171,7 @@ struct mocr_engine {
     }
     void prof_collect() {
         if (recs.empty()) return;
-        HIPCHECK(hipStreamSynchronize(stream));
+        HIPCHECK(hipDeviceSynchronize());
         for (auto& r : recs) {
             float ms = 0.f;
             HIPCHECK(hipEventElapsedTime(&ms, r.e0, r.e1));
@@ -417,7 +451,7 @@ template <typename T> void init_kernel_attrs() {
 // token, finished flags) lives in device memory, so the launch sequence is identical each step.
 template <typename T>
 hipGraphExec_t decode_graph(mocr_engine* e, const DecState& st, int n, int steps) {
-    const auto key = std::make_tuple(n, st.max_len, steps);
+    const auto key = std::make_tuple(e->lane_id, n, st.max_len, steps);
     auto it = e->graphs.find(key);
     if (it != e->graphs.end()) return it->second;
     hipGraph_t g = nullptr;
@@ -437,42 +471,134 @@ hipGraphExec_t decode_graph(mocr_engine* e, const DecState& st, int n, int steps
     return ge;
 }
 
-// Greedy loop.  Returns the number of steps launched.
+// Teacher-forced decode (test hook): eager launches, logits of every step kept.
 template <typename T>
-int run_decode(mocr_engine* e, int n, int max_len, const int* forced, int forced_T, float* logits_out, bool allow_sync) {
-    DecState st = make_state(e, max_len, forced, forced_T, logits_out);
+void run_decode_forced(mocr_engine* e, int n, const int* forced, int forced_T, float* logits_out) {
+    DecState st = make_state(e, e->cfg.max_len, forced, forced_T, logits_out);
     dec_token<T, true>(e, st, 0, n);
-    const int steps = forced ? forced_T : max_len - 1;
-    const bool early = allow_sync && !forced && !(e->cfg.flags & MOCR_FLAG_NO_EARLY_EXIT);
-    const bool use_graph = !forced && !e->prof_on && !(e->cfg.flags & MOCR_FLAG_NO_GRAPH);
-    constexpr int CH = 8;
-    int t = 0;
-    while (t < steps) {
-        if (use_graph) {
-            const int k = (steps - t >= CH) ? CH : 1;
-            HIPCHECK(hipGraphLaunch(decode_graph<T>(e, st, n, k), e->stream));
-            t += k;
-        } else {
-            decode_step<T>(e, st, n, t);
-            ++t;
-        }
-        if (early && (t % 16) == 0 && t < steps) {
-            HIPCHECK(hipMemcpyAsync(e->h_pinned, e->n_unf, sizeof(int), hipMemcpyDeviceToHost, e->stream));
-            HIPCHECK(hipStreamSynchronize(e->stream));
-            if (*e->h_pinned <= 0) break;
-        }
-    }
-    return t;
+    for (int t = 0; t < forced_T; ++t) decode_step<T>(e, st, n, t);
 }
 
+// ---------------------------------------------------------------------------------------- scheduler
+// A job moves through: start (input staging, encoder, cross-K/V, start token) -> chunks of CHUNK
+// greedy steps (one HIP-graph replay each) -> finish (copy ids/lengths out).  After each chunk the
+// lane's unfinished-row counter is copied to pinned memory; the flag of chunk c-2 is examined
+// before chunk c is enqueued, so a lane always has work queued while the host looks at a flag, and
+// a batch whose rows have all emitted EOS stops at most one chunk late.
+constexpr int CHUNK = 8;
+
 template <typename T>
-void recognize_batch(mocr_engine* e, const uint8_t* d_gray, int n, int max_len, bool allow_sync) {
-    run_encoder<T>(e, d_gray, n);
-    run_cross_kv<T>(e, n);
-    // ids rows must read pad_id beyond what the loop writes
-    HIPCHECK(hipMemsetAsync(e->ids, 0, (size_t)n * e->cfg.max_len * sizeof(int), e->stream));
-    if (e->cfg.pad_id != 0) throw ArgError{"pad_id != 0 is not supported", MOCR_ERR_UNSUPPORTED};
-    run_decode<T>(e, n, max_len, nullptr, 0, nullptr, allow_sync);
+void start_job(mocr_engine* e, Lane& L) {
+    const Job& j = L.job;
+    const int IMG = e->cfg.image_size;
+    const uint8_t* d_gray = j.src;
+    if (j.src_host) {
+        const size_t rowb = (size_t)IMG * j.channels;
+        uint8_t* dst = j.channels == 1 ? e->d_in : e->d_rgb;
+        if (j.row_stride == (int64_t)rowb && j.image_stride == (int64_t)(rowb * IMG)) {
+            HIPCHECK(hipMemcpyAsync(dst, j.src, rowb * IMG * j.n, hipMemcpyHostToDevice, e->stream));
+        } else {
+            for (int i = 0; i < j.n; ++i)
+                HIPCHECK(hipMemcpy2DAsync(dst + (size_t)i * IMG * rowb, rowb, j.src + (size_t)i * j.image_stride, j.row_stride,
+                                          rowb, IMG, hipMemcpyHostToDevice, e->stream));
+        }
+        if (j.channels == 3) {
+            const long long npix = (long long)j.n * IMG * IMG;
+            hipLaunchKernelGGL(rgb_to_l_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, e->stream, e->d_rgb, e->d_in, npix);
+            HIPCHECK(hipGetLastError());
+        }
+        d_gray = e->d_in;
+    }
+    run_encoder<T>(e, d_gray, j.n);
+    run_cross_kv<T>(e, j.n);
+    // rows read pad_id (= 0) beyond what the loop writes
+    HIPCHECK(hipMemsetAsync(e->ids, 0, (size_t)j.n * e->cfg.max_len * sizeof(int), e->stream));
+    DecState st = make_state(e, j.max_len, nullptr, 0, nullptr);
+    dec_token<T, true>(e, st, 0, j.n);
+    L.t = 0; L.steps = j.max_len - 1; L.chunk = 0;
+    L.flag_pending[0] = L.flag_pending[1] = false;
+}
+
+void finish_job(mocr_engine* e, Lane& L) {
+    const Job& j = L.job;
+    const hipMemcpyKind kind = j.out_host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    HIPCHECK(hipMemcpyAsync(j.out_ids, e->ids, (size_t)j.n * e->cfg.max_len * sizeof(int), kind, e->stream));
+    HIPCHECK(hipMemcpyAsync(j.out_len, e->len, (size_t)j.n * sizeof(int), kind, e->stream));
+    L.active = false;
+}
+
+// Enqueue the next chunk of lane L (or finish it).  Blocks only on a flag two chunks old.
+template <typename T>
+void advance(mocr_engine* e, Lane& L) {
+    const bool early = !(e->cfg.flags & MOCR_FLAG_NO_EARLY_EXIT);
+    const int slot = L.chunk & 1;
+    if (early && L.flag_pending[slot]) {
+        HIPCHECK(hipEventSynchronize(L.flag_ev[slot]));
+        L.flag_pending[slot] = false;
+        if (e->h_pinned[slot] <= 0) { finish_job(e, L); return; }
+    }
+    if (L.t >= L.steps) { finish_job(e, L); return; }
+    const Job& j = L.job;
+    DecState st = make_state(e, j.max_len, nullptr, 0, nullptr);
+    const int k = std::min(CHUNK, L.steps - L.t);
+    const bool use_graph = !e->prof_on && !(e->cfg.flags & MOCR_FLAG_NO_GRAPH);
+    if (use_graph && k == CHUNK) {
+        HIPCHECK(hipGraphLaunch(decode_graph<T>(e, st, j.n, CHUNK), e->stream));
+    } else {
+        for (int i = 0; i < k; ++i) {
+            if (use_graph) HIPCHECK(hipGraphLaunch(decode_graph<T>(e, st, j.n, 1), e->stream));
+            else decode_step<T>(e, st, j.n, L.t + i);
+        }
+    }
+    L.t += k;
+    if (early) {
+        HIPCHECK(hipMemcpyAsync(e->h_pinned + slot, e->n_unf, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+        HIPCHECK(hipEventRecord(L.flag_ev[slot], e->stream));
+        L.flag_pending[slot] = true;
+    }
+    L.chunk += 1;
+}
+
+// One scheduling pass over the lanes: idle lanes take a pending job, busy lanes get one chunk.
+template <typename T>
+bool pump_once(mocr_engine* e) {
+    bool any = false;
+    for (size_t i = 0; i < e->lanes.size(); ++i) {
+        Lane& L = e->lanes[i];
+        if (!L.active && !e->pending.empty()) {
+            L.job = e->pending.front();
+            e->pending.erase(e->pending.begin());
+            L.active = true;
+            e->bind((int)i);
+            start_job<T>(e, L);
+            e->unbind((int)i);
+        }
+        if (L.active) {
+            e->bind((int)i);
+            advance<T>(e, L);
+            e->unbind((int)i);
+            any = true;
+        }
+    }
+    return any || !e->pending.empty();
+}
+
+// Run every submitted job to completion and wait for the GPU.
+void drive(mocr_engine* e) {
+    try {
+        if (e->cfg.dtype == MOCR_BF16) { while (pump_once<bf16_t>(e)) {} }
+        else { while (pump_once<float>(e)) {} }
+    } catch (...) {
+        e->pending.clear();
+        for (auto& L : e->lanes) { L.active = false; (void)hipStreamSynchronize(L.ctx.stream); }
+        throw;
+    }
+    for (auto& L : e->lanes) HIPCHECK(hipStreamSynchronize(L.ctx.stream));
+}
+
+void submit(mocr_engine* e, const Job& j) {
+    e->pending.push_back(j);
+    if (e->cfg.dtype == MOCR_BF16) pump_once<bf16_t>(e); else pump_once<float>(e);
 }
 
 // ---------------------------------------------------------------------------------------- weights
@@ -615,7 +741,7 @@ void commit_weights(mocr_engine* e) {
     e->committed = true;
 }
 
-void allocate_workspace(mocr_engine* e) {
+void compute_geometry(mocr_engine* e) {
     const auto& c = e->cfg;
     e->S = (c.image_size / c.patch_size) * (c.image_size / c.patch_size) + 1;
     e->G = c.image_size / c.patch_size;
@@ -624,6 +750,14 @@ void allocate_workspace(mocr_engine* e) {
     e->Bp = round_up(c.max_batch, 128);
     e->Mp = round_up(c.max_batch * e->S, 128) + 128;
     e->NCKV = c.dec_layers * 2 * c.hidden;
+}
+
+// Workspace of ONE lane, allocated into the engine's bound LaneCtx (then saved with unbind()).
+void allocate_lane(mocr_engine* e, int lane_id) {
+    const auto& c = e->cfg;
+    static_cast<LaneCtx&>(*e) = LaneCtx{};
+    e->lane_id = lane_id;
+    HIPCHECK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     const size_t Mp = e->Mp, D = e->D, Bp = e->Bp, esz = e->esz;
     e->d_in = e->dalloc<uint8_t>((size_t)c.max_batch * c.image_size * c.image_size);
     e->d_rgb = e->dalloc<uint8_t>((size_t)c.max_batch * c.image_size * c.image_size * 3);
@@ -646,6 +780,19 @@ void allocate_workspace(mocr_engine* e) {
     e->ids = e->dalloc<int>(Bp * (size_t)c.max_len);
     e->step = e->dalloc<int>(Bp); e->finished = e->dalloc<int>(Bp); e->len = e->dalloc<int>(Bp); e->n_unf = e->dalloc<int>(4);
     HIPCHECK(hipHostMalloc(reinterpret_cast<void**>(&e->h_pinned), 64, hipHostMallocDefault));
+}
+
+void allocate_lanes(mocr_engine* e) {
+    compute_geometry(e);
+    const int nl = std::max(1, std::min(16, (int)e->cfg.lanes));
+    e->lanes.resize(nl);
+    for (int i = 0; i < nl; ++i) {
+        allocate_lane(e, i);
+        e->unbind(i);
+        HIPCHECK(hipEventCreateWithFlags(&e->lanes[i].flag_ev[0], hipEventDisableTiming));
+        HIPCHECK(hipEventCreateWithFlags(&e->lanes[i].flag_ev[1], hipEventDisableTiming));
+    }
+    e->bind(0);
 }
 
 template <typename F> int guarded(mocr_engine* e, F&& f) {
@@ -692,18 +839,19 @@ int mocr_create(const mocr_config* cfg, mocr_engine** out) {
     if (!cfg || !out || cfg->struct_size != (int32_t)sizeof(mocr_config)) return MOCR_ERR_ARG;
     if (cfg->hidden != 768 || cfg->heads != 12 || cfg->image_size != 224 || cfg->patch_size != 16 || cfg->ffn % 128 ||
         cfg->vocab != 6144 || cfg->max_len < 2 || cfg->max_len > 320 || cfg->max_len > cfg->max_pos || cfg->max_batch < 1 ||
-        (cfg->dtype != MOCR_F32 && cfg->dtype != MOCR_BF16) || cfg->enc_layers < 1 || cfg->dec_layers < 1)
+        (cfg->dtype != MOCR_F32 && cfg->dtype != MOCR_BF16) || cfg->enc_layers < 1 || cfg->dec_layers < 1 ||
+        cfg->pad_id != 0 || cfg->lanes < 0)
         return MOCR_ERR_UNSUPPORTED;
     mocr_engine* e = new (std::nothrow) mocr_engine();
     if (!e) return MOCR_ERR_NOMEM;
     e->cfg = *cfg;
+    if (e->cfg.lanes == 0) e->cfg.lanes = 1;
     int rc = guarded(e, [&] {
         int ndev = 0;
         HIPCHECK(hipGetDeviceCount(&ndev));
         if (ndev <= 0) throw ArgError{"no HIP device visible: the Manga-OCR engine needs a GPU", MOCR_ERR_HIP};
         HIPCHECK(hipSetDevice(cfg->device));
-        HIPCHECK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-        allocate_workspace(e);
+        allocate_lanes(e);
     });
     if (rc != MOCR_OK) {
         fprintf(stderr, "mocr_create failed: %s\n", e->err.c_str());
@@ -717,13 +865,17 @@ int mocr_create(const mocr_config* cfg, mocr_engine** out) {
 void mocr_destroy(mocr_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->cfg.device);
-    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (auto& L : e->lanes)
+        if (L.ctx.stream) (void)hipStreamSynchronize(L.ctx.stream);
     for (auto& r : e->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
     for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
     for (void* p : e->allocs) (void)hipFree(p);
-    if (e->h_pinned) (void)hipHostFree(e->h_pinned);
-    if (e->stream) (void)hipStreamDestroy(e->stream);
+    for (auto& L : e->lanes) {
+        if (L.ctx.h_pinned) (void)hipHostFree(L.ctx.h_pinned);
+        for (auto ev : L.flag_ev) if (ev) (void)hipEventDestroy(ev);
+        if (L.ctx.stream) (void)hipStreamDestroy(L.ctx.stream);
+    }
     delete e;
 }
 
@@ -750,10 +902,14 @@ int mocr_commit_weights(mocr_engine* e) {
     });
 }
 
-void* mocr_stream(mocr_engine* e) { return e ? (void*)e->stream : nullptr; }
+void* mocr_stream(mocr_engine* e) { return (e && !e->lanes.empty()) ? (void*)e->lanes[0].ctx.stream : nullptr; }
 
 int mocr_synchronize(mocr_engine* e) {
-    return guarded(e, [&] { HIPCHECK(hipSetDevice(e->cfg.device)); HIPCHECK(hipStreamSynchronize(e->stream)); });
+    return guarded(e, [&] {
+        std::lock_guard<std::mutex> lk(e->mu);
+        HIPCHECK(hipSetDevice(e->cfg.device));
+        drive(e);
+    });
 }
 
 int mocr_recognize_device(mocr_engine* e, const void* d_gray, int32_t n, void* d_out_ids, void* d_out_len) {
@@ -762,10 +918,11 @@ int mocr_recognize_device(mocr_engine* e, const void* d_gray, int32_t n, void* d
         require_ready(e, n);
         if (!d_gray || !d_out_ids || !d_out_len) throw ArgError{"null device pointer", MOCR_ERR_ARG};
         HIPCHECK(hipSetDevice(e->cfg.device));
-        const uint8_t* g = reinterpret_cast<const uint8_t*>(d_gray);
-        dispatch(e, [&](auto tag) { recognize_batch<decltype(tag)>(e, g, n, e->cfg.max_len, false); });
-        HIPCHECK(hipMemcpyAsync(d_out_ids, e->ids, (size_t)n * e->cfg.max_len * sizeof(int), hipMemcpyDeviceToDevice, e->stream));
-        HIPCHECK(hipMemcpyAsync(d_out_len, e->len, (size_t)n * sizeof(int), hipMemcpyDeviceToDevice, e->stream));
+        Job j;
+        j.src = reinterpret_cast<const uint8_t*>(d_gray); j.src_host = false;
+        j.n = n; j.max_len = e->cfg.max_len;
+        j.out_ids = reinterpret_cast<int32_t*>(d_out_ids); j.out_len = reinterpret_cast<int32_t*>(d_out_len); j.out_host = false;
+        submit(e, j);
     });
 }
 
@@ -777,24 +934,15 @@ static void recognize_host_chunks(mocr_engine* e, const uint8_t* images, int n, 
     if (channels != 1 && channels != 3) throw ArgError{"channels must be 1 (L) or 3 (RGB)", MOCR_ERR_ARG};
     if (!images || !out_ids || !out_len) throw ArgError{"null pointer", MOCR_ERR_ARG};
     if (max_len < 2 || max_len > e->cfg.max_len) throw ArgError{"bad max_len override", MOCR_ERR_ARG};
-    const size_t rowb = (size_t)IMG * channels;
     for (int base = 0; base < n; base += e->cfg.max_batch) {
-        const int nb = std::min(e->cfg.max_batch, n - base);
-        uint8_t* dst = channels == 1 ? e->d_in : e->d_rgb;
-        for (int i = 0; i < nb; ++i)
-            HIPCHECK(hipMemcpy2DAsync(dst + (size_t)i * IMG * rowb, rowb, images + (size_t)(base + i) * image_stride, row_stride,
-                                      rowb, IMG, hipMemcpyHostToDevice, e->stream));
-        if (channels == 3) {
-            const long long npix = (long long)nb * IMG * IMG;
-            hipLaunchKernelGGL(rgb_to_l_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, e->stream, e->d_rgb, e->d_in, npix);
-            HIPCHECK(hipGetLastError());
-        }
-        dispatch(e, [&](auto tag) { recognize_batch<decltype(tag)>(e, e->d_in, nb, max_len, true); });
-        HIPCHECK(hipMemcpyAsync(out_ids + (size_t)base * e->cfg.max_len, e->ids, (size_t)nb * e->cfg.max_len * sizeof(int),
-                                hipMemcpyDeviceToHost, e->stream));
-        HIPCHECK(hipMemcpyAsync(out_len + base, e->len, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, e->stream));
-        HIPCHECK(hipStreamSynchronize(e->stream));
+        Job j;
+        j.src = images + (size_t)base * image_stride; j.src_host = true; j.channels = channels;
+        j.row_stride = row_stride; j.image_stride = image_stride;
+        j.n = std::min(e->cfg.max_batch, n - base); j.max_len = max_len;
+        j.out_ids = out_ids + (size_t)base * e->cfg.max_len; j.out_len = out_len + base; j.out_host = true;
+        e->pending.push_back(j);
     }
+    drive(e);
 }
 
 int mocr_recognize(mocr_engine* e, const uint8_t* images, int32_t n, int32_t h, int32_t w, int64_t row_stride,
@@ -824,6 +972,8 @@ int mocr_encode(mocr_engine* e, const void* d_gray, int32_t n, float* h_out) {
         require_ready(e, n);
         if (!d_gray || !h_out) throw ArgError{"null pointer", MOCR_ERR_ARG};
         HIPCHECK(hipSetDevice(e->cfg.device));
+        drive(e);
+        e->bind(0);
         const uint8_t* g = reinterpret_cast<const uint8_t*>(d_gray);
         dispatch(e, [&](auto tag) { run_encoder<decltype(tag)>(e, g, n); });
         const size_t count = (size_t)n * e->S * e->D;
@@ -848,18 +998,20 @@ int mocr_decode_logits(mocr_engine* e, const void* d_gray, int32_t n, const int3
         require_ready(e, n);
         if (!d_gray || !forced_ids || !h_logits || T < 1 || T >= e->cfg.max_len) throw ArgError{"bad argument", MOCR_ERR_ARG};
         HIPCHECK(hipSetDevice(e->cfg.device));
+        drive(e);
+        e->bind(0);
         const size_t fcount = (size_t)n * T, lcount = (size_t)n * T * e->V;
         if (fcount > e->forced_cap) { e->forced = e->dalloc<int>(fcount); e->forced_cap = fcount; }
         if (lcount > e->logits_cap) { e->logits_dbg = e->dalloc<float>(lcount); e->logits_cap = lcount; }
+        e->unbind(0);
         HIPCHECK(hipMemcpyAsync(e->forced, forced_ids, fcount * sizeof(int), hipMemcpyHostToDevice, e->stream));
         const uint8_t* g = reinterpret_cast<const uint8_t*>(d_gray);
-        if (e->cfg.dtype == MOCR_BF16) {
-            run_encoder<bf16_t>(e, g, n); run_cross_kv<bf16_t>(e, n);
-            run_decode<bf16_t>(e, n, e->cfg.max_len, e->forced, T, e->logits_dbg, false);
-        } else {
-            run_encoder<float>(e, g, n); run_cross_kv<float>(e, n);
-            run_decode<float>(e, n, e->cfg.max_len, e->forced, T, e->logits_dbg, false);
-        }
+        dispatch(e, [&](auto tag) {
+            using T_ = decltype(tag);
+            run_encoder<T_>(e, g, n);
+            run_cross_kv<T_>(e, n);
+            run_decode_forced<T_>(e, n, e->forced, T, e->logits_dbg);
+        });
         HIPCHECK(hipMemcpyAsync(h_logits, e->logits_dbg, lcount * 4, hipMemcpyDeviceToHost, e->stream));
         HIPCHECK(hipStreamSynchronize(e->stream));
     });
@@ -870,6 +1022,8 @@ int mocr_op_gemm(mocr_engine* e, const void* dA, const void* dW, const float* d_
     return guarded(e, [&] {
         std::lock_guard<std::mutex> lk(e->mu);
         HIPCHECK(hipSetDevice(e->cfg.device));
+        drive(e);
+        e->bind(0);
         if (epilogue == EPI_PATCH) throw ArgError{"EPI_PATCH is not exposed through mocr_op_gemm", MOCR_ERR_ARG};
         const long long slab = (long long)M * N;
         if (e->cfg.dtype == MOCR_BF16)
@@ -884,6 +1038,8 @@ int mocr_op_layernorm(mocr_engine* e, const float* d_x, const float* d_gamma, co
     return guarded(e, [&] {
         std::lock_guard<std::mutex> lk(e->mu);
         HIPCHECK(hipSetDevice(e->cfg.device));
+        drive(e);
+        e->bind(0);
         dispatch(e, [&](auto tag) { layernorm<decltype(tag)>(e, d_x, d_gamma, d_beta, d_out, M); });
         HIPCHECK(hipStreamSynchronize(e->stream));
     });
@@ -893,6 +1049,8 @@ int mocr_op_enc_attention(mocr_engine* e, const void* d_qkv, void* d_ctx, int32_
     return guarded(e, [&] {
         std::lock_guard<std::mutex> lk(e->mu);
         HIPCHECK(hipSetDevice(e->cfg.device));
+        drive(e);
+        e->bind(0);
         dispatch(e, [&](auto tag) { enc_attention<decltype(tag)>(e, d_qkv, d_ctx, n, impl); });
         HIPCHECK(hipStreamSynchronize(e->stream));
     });
@@ -902,6 +1060,7 @@ int mocr_profile_enable(mocr_engine* e, int32_t on) {
     return guarded(e, [&] {
         std::lock_guard<std::mutex> lk(e->mu);
         HIPCHECK(hipSetDevice(e->cfg.device));
+        drive(e);
         e->prof_collect();
         e->prof_on = on != 0;
     });
@@ -911,6 +1070,7 @@ int mocr_profile_reset(mocr_engine* e) {
     return guarded(e, [&] {
         std::lock_guard<std::mutex> lk(e->mu);
         HIPCHECK(hipSetDevice(e->cfg.device));
+        drive(e);
         e->prof_collect();
         for (auto& s : e->stats) { s.launches = 0; s.total_ms = 0; s.flops = 0; s.bytes = 0; }
     });
@@ -921,6 +1081,7 @@ int mocr_profile_get(mocr_engine* e, mocr_kernel_stat* out, int32_t cap, int32_t
         std::lock_guard<std::mutex> lk(e->mu);
         if (!out || !n_out || cap < 0) throw ArgError{"bad argument", MOCR_ERR_ARG};
         HIPCHECK(hipSetDevice(e->cfg.device));
+        drive(e);
         e->prof_collect();
         int k = 0;
         for (auto& s : e->stats)

@@ -19,7 +19,7 @@ class MocrConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "struct_size", "device", "dtype", "max_batch", "max_len", "image_size", "patch_size", "hidden",
         "enc_layers", "dec_layers", "heads", "ffn", "vocab", "max_pos", "start_id", "eos_id", "pad_id")] + \
-        [("ln_eps", C.c_float), ("flags", C.c_int32)]
+        [("ln_eps", C.c_float), ("flags", C.c_int32), ("lanes", C.c_int32)]
 
 
 class MocrKernelStat(C.Structure):

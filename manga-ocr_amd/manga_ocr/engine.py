@@ -30,7 +30,8 @@ class Engine:
     """One engine = one GPU = one HIP stream.  Thread-safe (calls are serialised natively)."""
 
     def __init__(self, weights: Dict[str, np.ndarray], spec: ModelSpec = DEFAULT_SPEC, *, dtype: str = "bf16",
-                 device: int = 0, max_batch: int = 64, flags: int = 0, lib_path: Optional[str] = None):
+                 device: int = 0, max_batch: int = 64, flags: int = 0, lanes: int = 1,
+                 lib_path: Optional[str] = None):
         self.lib = _capi.load_library(lib_path)
         self.spec = spec
         self.dtype = dtype
@@ -42,7 +43,7 @@ class Engine:
             max_len=spec.max_len, image_size=spec.image_size, patch_size=spec.patch_size, hidden=spec.hidden,
             enc_layers=spec.enc_layers, dec_layers=spec.dec_layers, heads=spec.heads, ffn=spec.ffn, vocab=spec.vocab,
             max_pos=spec.max_pos, start_id=spec.start_id, eos_id=spec.eos_id, pad_id=spec.pad_id,
-            ln_eps=spec.ln_eps, flags=flags)
+            ln_eps=spec.ln_eps, flags=flags, lanes=lanes)
         h = C.c_void_p()
         rc = self.lib.mocr_create(C.byref(cfg), C.byref(h))
         if rc != _capi.MOCR_OK or not h.value:

@@ -29,9 +29,9 @@ def weights(seed=0, eos_bias=0.0):
 
 
 @functools.lru_cache(maxsize=None)
-def engine(dtype="fp32", seed=0, eos_bias=0.0, max_batch=8, flags=0):
+def engine(dtype="fp32", seed=0, eos_bias=0.0, max_batch=8, flags=0, lanes=1):
     from manga_ocr.engine import Engine
-    return Engine(weights(seed, eos_bias), DEFAULT_SPEC, dtype=dtype, device=0, max_batch=max_batch, flags=flags)
+    return Engine(weights(seed, eos_bias), DEFAULT_SPEC, dtype=dtype, device=0, max_batch=max_batch, flags=flags, lanes=lanes)
 
 
 @functools.lru_cache(maxsize=None)

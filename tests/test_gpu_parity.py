@@ -157,15 +157,32 @@ def test_batch_larger_than_max_batch_and_determinism():
     np.testing.assert_array_equal(a[8:], c)                   # a row's result does not depend on its batch
 
 
+def test_lanes_give_the_same_rows_as_one_lane(golden_dir):
+    """Batches in flight on several lanes (streams + workspaces) must not change any row, and the
+    chunked early-exit scheduler must stop each batch independently."""
+    g = np.load(os.path.join(golden_dir, "early_eos_seed1.npz"))
+    one = engine("fp32", seed=1, eos_bias=1.1, max_batch=2, lanes=1)
+    many = engine("fp32", seed=1, eos_bias=1.1, max_batch=2, lanes=3)
+    gray = crops(4321, 6)                                     # 3 jobs of 2 rows: rows finish at 31..106 tokens
+    a, la = one.recognize(gray)
+    b, lb = many.recognize(gray)
+    np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(la, lb)
+    L = g["ids"].shape[1]
+    np.testing.assert_array_equal(b[:, :L], g["ids"])
+    report(f"3-lane scheduler vs 1 lane vs transformers golden (early EOS): identical, lens {lb.tolist()}")
+
+
 def test_device_resident_entry_point_matches_host_entry_point():
-    eng = engine("bf16", flags=4)                             # NO_EARLY_EXIT: the async path runs all steps
-    gray = crops(5, 3)
+    eng = engine("bf16", lanes=2)
+    gray = crops(5, 6)
     ids_h, len_h = eng.recognize(gray)
     d_gray = _dgray(gray)
-    d_ids = torch.zeros((3, 300), dtype=torch.int32, device="cuda")
-    d_len = torch.zeros(3, dtype=torch.int32, device="cuda")
+    d_ids = torch.zeros((6, 300), dtype=torch.int32, device="cuda")
+    d_len = torch.zeros(6, dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()
-    eng.recognize_device(d_gray, 3, d_ids, d_len)
+    eng.recognize_device(d_gray[:3], 3, d_ids[:3], d_len[:3])      # two batches in flight
+    eng.recognize_device(d_gray[3:], 3, d_ids[3:], d_len[3:])
     eng.synchronize()
     np.testing.assert_array_equal(d_ids.cpu().numpy(), ids_h)
     np.testing.assert_array_equal(d_len.cpu().numpy(), len_h)
