@@ -65,12 +65,13 @@ def cpu_baseline(args, weights):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--batch", type=int, default=64, help="crops per GPU per step (BASELINE configs[1]: 64)")
     ap.add_argument("--max-len", type=int, default=300)
     ap.add_argument("--dtype", default="bf16")
-    ap.add_argument("--lanes", type=int, default=4, help="batches the engine keeps in flight (streams + workspaces)")
+    ap.add_argument("--lanes", type=int, default=2, help="internal batches the engine keeps in flight (streams + workspaces)")
+    ap.add_argument("--max-batch", type=int, default=512, help="rows of one internal engine batch: submitted steps are merged up to this")
     ap.add_argument("--cpu-sample", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
@@ -97,7 +98,8 @@ def main():
 
     spec = dataclasses.replace(DEFAULT_SPEC, max_len=args.max_len)
     weights = synthetic_weights(0)
-    eng = Engine(weights, spec, dtype=args.dtype, device=local, max_batch=args.batch, lanes=args.lanes)
+    args.max_batch = max(args.max_batch, args.batch)
+    eng = Engine(weights, spec, dtype=args.dtype, device=local, max_batch=args.max_batch, lanes=args.lanes)
     B, L = args.batch, args.max_len
     # this rank's shard of the crop queue: global crop ids [rank*B, (rank+1)*B) of every step
     gray = np.random.RandomState(1234 + rank).randint(0, 256, size=(B, 224, 224), dtype=np.uint8)
@@ -140,10 +142,10 @@ def main():
     if rank == 0 and not args.no_profile:
         eng.profile_enable(True)
         eng.profile_reset()
-        psteps = max(1, min(2, args.steps))
-        for i in range(psteps):          # one batch at a time: kernel durations free of overlap
+        psteps = max(1, min(args.max_batch // B, args.steps))   # ONE merged internal batch: durations free of overlap
+        for i in range(psteps):
             eng.recognize_device(d_gray, B, d_ids[i % K], d_len[i % K])
-            eng.synchronize()
+        eng.synchronize()
         stats = eng.profile_get()
         eng.profile_enable(False)
         tot = sum(s["total_ms"] for s in stats)
@@ -176,7 +178,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: batch={B} synthetic 224x224 crops per GPU per step, ViT-B/16 encoder + "
                                    f"2-layer BERT decoder, greedy decode max_len={L} (T={T} steps, EOS never fires with synthetic weights)",
-                       "global_batch": world * B, "lanes": args.lanes, "max_len": L, "decode_steps": T, "parallelism": f"dp{world}",
+                       "global_batch": world * B, "engine_max_batch": args.max_batch, "lanes": args.lanes, "max_len": L, "decode_steps": T, "parallelism": f"dp{world}",
                        "weights": "synthetic seed 0"},
             "algorithmic_gflop_per_crop": (ENC_FLOPS_PER_CROP + dec_flops_per_crop(T)) / 1e9,
             "roofline": roof, "cpu_baseline": cpu, "kernels": kernels[:12],

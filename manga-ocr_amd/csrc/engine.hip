@@ -108,7 +108,8 @@ struct Job {
 struct Lane {
     LaneCtx ctx;
     bool active = false;
-    Job job;
+    std::vector<Job> jobs;          // requests merged into this lane's current batch, in row order
+    int n = 0, max_len = 0;         // rows of the merged batch, its generate(max_length)
     int t = 0, steps = 0, chunk = 0;
     bool flag_pending[2] = {false, false};
     hipEvent_t flag_ev[2] = {nullptr, nullptr};
@@ -304,15 +305,15 @@ void run_encoder(mocr_engine* e, const uint8_t* d_gray, int n) {
 
 // ---------------------------------------------------------------------------------------- decoder
 static int pick_split(int N, int K, int kt, int rows, long long slab_cap_per_row) {
-    // enough blocks to cover the chip (64x64 tiles), bounded by K-tiles and the slab buffer
+    // 64x64 output tiles; split K until ~150-200 blocks cover the chip, bounded by the K-tiles and
+    // by the slab buffer.  Every extra slab is an fp32 [rows,N] write plus a read by the consumer,
+    // so fat batches (many row tiles) split less.
     const int tiles = (N / 64) * ((rows + 63) / 64);
-    int split = 1;
     const int ktiles = K / kt;
-    while (split * 2 <= ktiles && ktiles % (split * 2) == 0 && tiles * split < 384 &&
-           (long long)(split * 2) * N <= slab_cap_per_row)
+    int split = 1;
+    while (tiles * split < 150 && split * 2 <= ktiles && ktiles % (split * 2) == 0 && (long long)(split * 2) * N <= slab_cap_per_row)
         split *= 2;
-    // K = 768 has 12 (bf16) or 24 (fp32) K-tiles: allow the factor 3 as well
-    if (ktiles % (split * 3) == 0 && tiles * split < 256 && (long long)(split * 3) * N <= slab_cap_per_row) split *= 3;
+    if (tiles * split < 100 && ktiles % (split * 3) == 0 && (long long)(split * 3) * N <= slab_cap_per_row) split *= 3;
     return split;
 }
 
@@ -383,8 +384,18 @@ void dec_attn(mocr_engine* e, int layer, int nslab, int n, const float* bias, in
     p.ctx = e->ctx_t; p.H = H; p.scale = 0.125f;
     ProfScope ps(e, SELF ? "dec_attn_self" : "dec_attn_cross", 4.0 * n * H * approx_len * 64,
                  2.0 * n * H * approx_len * 64 * sizeof(T));
-    if (e->cfg.max_len > 320) throw ArgError{"max_len > 320 needs a larger NG", MOCR_ERR_UNSUPPORTED};
-    hipLaunchKernelGGL((dec_attn_kernel<T, SELF, (SELF ? 10 : 7)>), dim3(n * H), dim3(256), 0, e->stream, p);
+    if (SELF) {
+        // NG = 8-key groups a wave may own: pick the smallest variant that covers approx_len keys
+        // (approx_len is an upper bound of every row's context length during this launch)
+        const int need = ((approx_len + 3) / 4 + 7) / 8;
+        if (need <= 3) hipLaunchKernelGGL((dec_attn_kernel<T, true, 3>), dim3(n * H), dim3(256), 0, e->stream, p);
+        else if (need <= 5) hipLaunchKernelGGL((dec_attn_kernel<T, true, 5>), dim3(n * H), dim3(256), 0, e->stream, p);
+        else if (need <= 8) hipLaunchKernelGGL((dec_attn_kernel<T, true, 8>), dim3(n * H), dim3(256), 0, e->stream, p);
+        else if (need <= 10) hipLaunchKernelGGL((dec_attn_kernel<T, true, 10>), dim3(n * H), dim3(256), 0, e->stream, p);
+        else throw ArgError{"max_len > 320 needs a larger NG", MOCR_ERR_UNSUPPORTED};
+    } else {
+        hipLaunchKernelGGL((dec_attn_kernel<T, false, 7>), dim3(n * H), dim3(256), 0, e->stream, p);
+    }
     HIPCHECK(hipGetLastError());
 }
 
@@ -398,15 +409,17 @@ void decode_step(mocr_engine* e, const DecState& st, int n, int t) {
     for (int l = 0; l < e->cfg.dec_layers; ++l) {
         const DecLayerW& L = w.dec[l];
         int ns = dec_gemm<T>(e, "gemm_dec_qkv", xin, D, L.wqkv, 3 * D, D, n);
-        dec_attn<T, true>(e, l, ns, n, L.bqkv, t + 1);
+        dec_attn<T, true>(e, l, ns, n, L.bqkv, t + 1);   // t = step index = keys already cached
         ns = dec_gemm<T>(e, "gemm_dec_proj", e->ctx_t, D, L.wo, D, D, n);
         dec_add_ln<T>(e, ns, D, L.bo, xres, L.ln1g, L.ln1b, e->a_f32, e->a_t, n, false);
         ns = dec_gemm<T>(e, "gemm_dec_proj", e->a_t, D, L.wqc, D, D, n);
         dec_attn<T, false>(e, l, ns, n, L.bqc, e->S);
         ns = dec_gemm<T>(e, "gemm_dec_proj", e->ctx_t, D, L.woc, D, D, n);
         dec_add_ln<T>(e, ns, D, L.boc, e->a_f32, L.ln2g, L.ln2b, e->c_f32, e->c_t, n, false);
-        ns = dec_gemm<T>(e, "gemm_dec_fc1", e->c_t, D, L.w1, F, D, n);
-        {
+        if (pick_split(F, D, 128 / (int)sizeof(T), n, e->slab_cap / e->Bp) == 1) {
+            gemm<T>(e, "gemm_dec_fc1", e->c_t, D, L.w1, L.b1, e->h_t, F, nullptr, n, F, D, EPI_BIAS_GELU, 64, 1);
+        } else {
+            ns = dec_gemm<T>(e, "gemm_dec_fc1", e->c_t, D, L.w1, F, D, n);
             ProfScope ps(e, "dec_bias_gelu", 0, (double)n * F * (4.0 * ns + sizeof(T)));
             hipLaunchKernelGGL((dec_bias_gelu_kernel<T>), dim3((n * F / 4 + 255) / 256), dim3(256), 0, e->stream, e->slabs, ns,
                                (long long)e->Bp * F, L.b1, reinterpret_cast<T*>(e->h_t), n, F);
@@ -450,14 +463,18 @@ template <typename T> void init_kernel_attrs() {
 // `steps` consecutive greedy steps captured once and replayed: every per-step value (position,
 // token, finished flags) lives in device memory, so the launch sequence is identical each step.
 template <typename T>
-hipGraphExec_t decode_graph(mocr_engine* e, const DecState& st, int n, int steps) {
-    const auto key = std::make_tuple(e->lane_id, n, st.max_len, steps);
+hipGraphExec_t decode_graph(mocr_engine* e, const DecState& st, int n, int steps, int t0) {
+    // the self-attention variant depends on the context length, so graphs are bucketed by it
+    const int need = ((t0 + steps + 3) / 4 + 7) / 8;
+    const int bucket = need <= 3 ? 3 : need <= 5 ? 5 : need <= 8 ? 8 : 10;
+    const int t_hi = std::min(bucket * 32, st.max_len) - 1;      // largest context this bucket covers
+    const auto key = std::make_tuple(e->lane_id, n, st.max_len * 16 + bucket, steps);
     auto it = e->graphs.find(key);
     if (it != e->graphs.end()) return it->second;
     hipGraph_t g = nullptr;
     HIPCHECK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
     try {
-        for (int i = 0; i < steps; ++i) decode_step<T>(e, st, n, 0);
+        for (int i = 0; i < steps; ++i) decode_step<T>(e, st, n, t_hi - 1);
     } catch (...) {
         (void)hipStreamEndCapture(e->stream, &g);
         if (g) (void)hipGraphDestroy(g);
@@ -488,42 +505,51 @@ void run_decode_forced(mocr_engine* e, int n, const int* forced, int forced_T, f
 constexpr int CHUNK = 8;
 
 template <typename T>
-void start_job(mocr_engine* e, Lane& L) {
-    const Job& j = L.job;
+void start_batch(mocr_engine* e, Lane& L) {
     const int IMG = e->cfg.image_size;
-    const uint8_t* d_gray = j.src;
-    if (j.src_host) {
-        const size_t rowb = (size_t)IMG * j.channels;
-        uint8_t* dst = j.channels == 1 ? e->d_in : e->d_rgb;
-        if (j.row_stride == (int64_t)rowb && j.image_stride == (int64_t)(rowb * IMG)) {
-            HIPCHECK(hipMemcpyAsync(dst, j.src, rowb * IMG * j.n, hipMemcpyHostToDevice, e->stream));
+    const size_t plane = (size_t)IMG * IMG;
+    int row0 = 0;
+    for (const Job& j : L.jobs) {
+        uint8_t* gdst = e->d_in + (size_t)row0 * plane;
+        if (!j.src_host) {
+            HIPCHECK(hipMemcpyAsync(gdst, j.src, plane * j.n, hipMemcpyDeviceToDevice, e->stream));
         } else {
-            for (int i = 0; i < j.n; ++i)
-                HIPCHECK(hipMemcpy2DAsync(dst + (size_t)i * IMG * rowb, rowb, j.src + (size_t)i * j.image_stride, j.row_stride,
-                                          rowb, IMG, hipMemcpyHostToDevice, e->stream));
+            const size_t rowb = (size_t)IMG * j.channels;
+            uint8_t* dst = j.channels == 1 ? gdst : e->d_rgb + (size_t)row0 * plane * 3;
+            if (j.row_stride == (int64_t)rowb && j.image_stride == (int64_t)(rowb * IMG)) {
+                HIPCHECK(hipMemcpyAsync(dst, j.src, rowb * IMG * j.n, hipMemcpyHostToDevice, e->stream));
+            } else {
+                for (int i = 0; i < j.n; ++i)
+                    HIPCHECK(hipMemcpy2DAsync(dst + (size_t)i * IMG * rowb, rowb, j.src + (size_t)i * j.image_stride, j.row_stride,
+                                              rowb, IMG, hipMemcpyHostToDevice, e->stream));
+            }
+            if (j.channels == 3) {
+                const long long npix = (long long)j.n * IMG * IMG;
+                hipLaunchKernelGGL(rgb_to_l_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, e->stream, dst, gdst, npix);
+                HIPCHECK(hipGetLastError());
+            }
         }
-        if (j.channels == 3) {
-            const long long npix = (long long)j.n * IMG * IMG;
-            hipLaunchKernelGGL(rgb_to_l_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, e->stream, e->d_rgb, e->d_in, npix);
-            HIPCHECK(hipGetLastError());
-        }
-        d_gray = e->d_in;
+        row0 += j.n;
     }
-    run_encoder<T>(e, d_gray, j.n);
-    run_cross_kv<T>(e, j.n);
+    run_encoder<T>(e, e->d_in, L.n);
+    run_cross_kv<T>(e, L.n);
     // rows read pad_id (= 0) beyond what the loop writes
-    HIPCHECK(hipMemsetAsync(e->ids, 0, (size_t)j.n * e->cfg.max_len * sizeof(int), e->stream));
-    DecState st = make_state(e, j.max_len, nullptr, 0, nullptr);
-    dec_token<T, true>(e, st, 0, j.n);
-    L.t = 0; L.steps = j.max_len - 1; L.chunk = 0;
+    HIPCHECK(hipMemsetAsync(e->ids, 0, (size_t)L.n * e->cfg.max_len * sizeof(int), e->stream));
+    DecState st = make_state(e, L.max_len, nullptr, 0, nullptr);
+    dec_token<T, true>(e, st, 0, L.n);
+    L.t = 0; L.steps = L.max_len - 1; L.chunk = 0;
     L.flag_pending[0] = L.flag_pending[1] = false;
 }
 
-void finish_job(mocr_engine* e, Lane& L) {
-    const Job& j = L.job;
-    const hipMemcpyKind kind = j.out_host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
-    HIPCHECK(hipMemcpyAsync(j.out_ids, e->ids, (size_t)j.n * e->cfg.max_len * sizeof(int), kind, e->stream));
-    HIPCHECK(hipMemcpyAsync(j.out_len, e->len, (size_t)j.n * sizeof(int), kind, e->stream));
+void finish_batch(mocr_engine* e, Lane& L) {
+    int row0 = 0;
+    for (const Job& j : L.jobs) {
+        const hipMemcpyKind kind = j.out_host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+        HIPCHECK(hipMemcpyAsync(j.out_ids, e->ids + (size_t)row0 * e->cfg.max_len, (size_t)j.n * e->cfg.max_len * sizeof(int), kind, e->stream));
+        HIPCHECK(hipMemcpyAsync(j.out_len, e->len + row0, (size_t)j.n * sizeof(int), kind, e->stream));
+        row0 += j.n;
+    }
+    L.jobs.clear();
     L.active = false;
 }
 
@@ -535,19 +561,18 @@ void advance(mocr_engine* e, Lane& L) {
     if (early && L.flag_pending[slot]) {
         HIPCHECK(hipEventSynchronize(L.flag_ev[slot]));
         L.flag_pending[slot] = false;
-        if (e->h_pinned[slot] <= 0) { finish_job(e, L); return; }
+        if (e->h_pinned[slot] <= 0) { finish_batch(e, L); return; }
     }
-    if (L.t >= L.steps) { finish_job(e, L); return; }
-    const Job& j = L.job;
-    DecState st = make_state(e, j.max_len, nullptr, 0, nullptr);
+    if (L.t >= L.steps) { finish_batch(e, L); return; }
+    DecState st = make_state(e, L.max_len, nullptr, 0, nullptr);
     const int k = std::min(CHUNK, L.steps - L.t);
     const bool use_graph = !e->prof_on && !(e->cfg.flags & MOCR_FLAG_NO_GRAPH);
     if (use_graph && k == CHUNK) {
-        HIPCHECK(hipGraphLaunch(decode_graph<T>(e, st, j.n, CHUNK), e->stream));
+        HIPCHECK(hipGraphLaunch(decode_graph<T>(e, st, L.n, CHUNK, L.t), e->stream));
     } else {
         for (int i = 0; i < k; ++i) {
-            if (use_graph) HIPCHECK(hipGraphLaunch(decode_graph<T>(e, st, j.n, 1), e->stream));
-            else decode_step<T>(e, st, j.n, L.t + i);
+            if (use_graph) HIPCHECK(hipGraphLaunch(decode_graph<T>(e, st, L.n, 1, L.t + i), e->stream));
+            else decode_step<T>(e, st, L.n, L.t + i);
         }
     }
     L.t += k;
@@ -559,18 +584,28 @@ void advance(mocr_engine* e, Lane& L) {
     L.chunk += 1;
 }
 
-// One scheduling pass over the lanes: idle lanes take a pending job, busy lanes get one chunk.
+// One scheduling pass over the lanes: an idle lane takes as many pending requests as fit in
+// max_batch rows (FIFO, same max_len) and runs them as ONE batch; busy lanes get one chunk.
 template <typename T>
 bool pump_once(mocr_engine* e) {
     bool any = false;
     for (size_t i = 0; i < e->lanes.size(); ++i) {
         Lane& L = e->lanes[i];
         if (!L.active && !e->pending.empty()) {
-            L.job = e->pending.front();
-            e->pending.erase(e->pending.begin());
+            L.jobs.clear();
+            L.n = 0;
+            L.max_len = e->pending.front().max_len;
+            size_t take = 0;
+            while (take < e->pending.size() && e->pending[take].max_len == L.max_len &&
+                   L.n + e->pending[take].n <= e->cfg.max_batch) {
+                L.n += e->pending[take].n;
+                L.jobs.push_back(e->pending[take]);
+                ++take;
+            }
+            e->pending.erase(e->pending.begin(), e->pending.begin() + take);
             L.active = true;
             e->bind((int)i);
-            start_job<T>(e, L);
+            start_batch<T>(e, L);
             e->unbind((int)i);
         }
         if (L.active) {
@@ -590,7 +625,7 @@ void drive(mocr_engine* e) {
         else { while (pump_once<float>(e)) {} }
     } catch (...) {
         e->pending.clear();
-        for (auto& L : e->lanes) { L.active = false; (void)hipStreamSynchronize(L.ctx.stream); }
+        for (auto& L : e->lanes) { L.active = false; L.jobs.clear(); (void)hipStreamSynchronize(L.ctx.stream); }
         throw;
     }
     for (auto& L : e->lanes) HIPCHECK(hipStreamSynchronize(L.ctx.stream));
@@ -598,7 +633,11 @@ void drive(mocr_engine* e) {
 
 void submit(mocr_engine* e, const Job& j) {
     e->pending.push_back(j);
-    if (e->cfg.dtype == MOCR_BF16) pump_once<bf16_t>(e); else pump_once<float>(e);
+    long long rows = 0;
+    for (const Job& p : e->pending) rows += p.n;
+    if (rows >= e->cfg.max_batch) {   // a full batch is waiting: get the GPU going; else wait for more to merge
+        if (e->cfg.dtype == MOCR_BF16) pump_once<bf16_t>(e); else pump_once<float>(e);
+    }
 }
 
 // ---------------------------------------------------------------------------------------- weights
