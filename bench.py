@@ -163,8 +163,18 @@ def main():
                             "share": s["total_ms"] / tot, "bound": "mfma" if mf else "hbm", "achieved": ach,
                             "peak": peak, "unit": unit, "frac": ach / peak})
         k0 = kernels[0]
+        traffic = None
+        try:   # HBM bytes per launch from the committed PMC passes (tools/summarize_profiles.py), same config only
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            sym = {"dec_attn_cross": "dec_attn_kernel<unsigned short, false", "dec_attn_self": "dec_attn_kernel<unsigned short, true"}.get(k0["kernel"])
+            if sym and args.dtype == "bf16" and args.max_batch == 512 and args.max_len == 300:
+                hit = [v for k, v in pm["kernels"].items() if sym in k]
+                if hit:
+                    traffic = sum(v["traffic_bytes"] * v["launches"] for v in hit) / sum(v["launches"] for v in hit)
+        except (OSError, ValueError, KeyError):
+            pass
         roof = {"kernel": k0["kernel"], "bound": k0["bound"], "achieved": k0["achieved"], "peak": k0["peak"],
-                "unit": k0["unit"], "frac": k0["frac"], "traffic": None, "avg_us": k0["avg_us"], "share_of_step": k0["share"]}
+                "unit": k0["unit"], "frac": k0["frac"], "traffic": traffic, "avg_us": k0["avg_us"], "share_of_step": k0["share"]}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
