@@ -107,7 +107,7 @@ def main():
     K = max(args.steps, args.warmup, 1)
     d_ids = torch.zeros((K, B, L), dtype=torch.int32, device="cuda")      # one output block per step
     d_len = torch.zeros((K, B), dtype=torch.int32, device="cuda")
-    d_all = torch.zeros((world, K, B, L), dtype=torch.int32, device="cuda") if world > 1 else None
+    d_all = torch.zeros((world * K, B, L), dtype=torch.int32, device="cuda") if world > 1 else None
     torch.cuda.synchronize()
 
     def run(nsteps):
