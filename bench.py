@@ -65,13 +65,13 @@ def cpu_baseline(args, weights):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
-    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--batch", type=int, default=64, help="crops per GPU per step (BASELINE configs[1]: 64)")
     ap.add_argument("--max-len", type=int, default=300)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--lanes", type=int, default=2, help="internal batches the engine keeps in flight (streams + workspaces)")
-    ap.add_argument("--max-batch", type=int, default=512, help="rows of one internal engine batch: submitted steps are merged up to this")
+    ap.add_argument("--max-batch", type=int, default=2048, help="rows of one internal engine batch: submitted steps are merged up to this")
     ap.add_argument("--cpu-sample", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
@@ -167,7 +167,7 @@ def main():
         try:   # HBM bytes per launch from the committed PMC passes (tools/summarize_profiles.py), same config only
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
             sym = {"dec_attn_cross": "dec_attn_kernel<unsigned short, false", "dec_attn_self": "dec_attn_kernel<unsigned short, true"}.get(k0["kernel"])
-            if sym and args.dtype == "bf16" and args.max_batch == 512 and args.max_len == 300:
+            if sym and args.dtype == "bf16" and args.max_len == 300:
                 hit = [v for k, v in pm["kernels"].items() if sym in k]
                 if hit:
                     traffic = sum(v["traffic_bytes"] * v["launches"] for v in hit) / sum(v["launches"] for v in hit)

@@ -77,6 +77,24 @@ __device__ __forceinline__ float wave_max(float v) {
 // exact-erf GELU (hidden_act="gelu"): 0.5 x (1 + erf(x / sqrt(2)))
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
+// Same function with erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below bf16
+// resolution): one v_rcp, one v_exp and a degree-5 Horner chain instead of libm's erff.  Used
+// where the result is stored as bf16; the fp32 parity mode keeps erff.
+__device__ __forceinline__ float gelu_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+    float p = 1.061405429f;
+    p = p * t - 1.453152027f;
+    p = p * t + 1.421413741f;
+    p = p * t - 0.284496736f;
+    p = p * t + 0.254829592f;
+    const float e = 1.0f - p * t * __expf(-z * z);      // erf(z), z >= 0
+    return 0.5f * x * (1.0f + copysignf(e, x));
+}
+template <typename T> __device__ __forceinline__ float gelu_for(float x) {
+    if constexpr (sizeof(T) == 2) return gelu_fast(x); else return gelu_erf(x);
+}
+
 // Async global -> LDS copy, 16 bytes per lane.  `lds_wave_base` must be wave-uniform: the
 // hardware writes lane i's 16 bytes at lds_wave_base + 16*i (cdna_hip_programming.md §5).
 __device__ __forceinline__ void glds16(const void* gsrc_lane, void* lds_wave_base) {

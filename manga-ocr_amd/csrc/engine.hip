@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -192,19 +193,28 @@ struct ProfScope {
     ~ProfScope() { e->prof_end(); }
 };
 
+// Tuning knobs (environment overrides are for experiments; defaults are the measured best).
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
 template <typename K> void set_max_lds(K kernel, int bytes) {
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
 }
 
 // ---------------------------------------------------------------------------------------- GEMM
+template <int BM> constexpr int gemm_ring() { return 2; }   // LDS ring depth per tile size
+
 template <typename T, int BM, int BN, int EPI>
 void launch_gemm_t(mocr_engine* e, const GemmParams& p0, int split) {
     GemmParams p = p0;
     p.ntn = p.N / BN;
     const int ntm = (p.M + BM - 1) / BM;
-    constexpr int lds = 2 * (BM + BN) * 128;
+    constexpr int NST = gemm_ring<BM>();
+    constexpr int lds = NST * (BM + BN) * 128;
     dim3 grid(ntm * p.ntn, 1, split);
-    hipLaunchKernelGGL((gemm_kernel<T, BM, BN, EPI>), grid, dim3(256), lds, e->stream, p);
+    hipLaunchKernelGGL((gemm_kernel<T, BM, BN, EPI, NST>), grid, dim3(256), lds, e->stream, p);
     HIPCHECK(hipGetLastError());
 }
 
@@ -221,25 +231,50 @@ void launch_gemm_epi(mocr_engine* e, const GemmParams& p, int epi, int split) {
     }
 }
 
-// A [M,K] (lda), W [N,K] (ldw=K), out (ldo).  tile: 128 or 64.  split > 1 only with EPI_SLAB.
+template <int EPI>
+void launch_gemm256_t(mocr_engine* e, const GemmParams& p0) {
+    GemmParams p = p0;
+    p.ntn = p.N / 128;
+    const int ntm = (p.M + 255) / 256;
+    hipLaunchKernelGGL((gemm256_kernel<EPI>), dim3(ntm * p.ntn), dim3(256), 3 * (256 + 128) * 128, e->stream, p);
+    HIPCHECK(hipGetLastError());
+}
+
+void launch_gemm256(mocr_engine* e, const GemmParams& p, int epi) {
+    switch (epi) {
+        case EPI_BIAS: launch_gemm256_t<EPI_BIAS>(e, p); break;
+        case EPI_BIAS_GELU: launch_gemm256_t<EPI_BIAS_GELU>(e, p); break;
+        case EPI_BIAS_RESID: launch_gemm256_t<EPI_BIAS_RESID>(e, p); break;
+        case EPI_PATCH: launch_gemm256_t<EPI_PATCH>(e, p); break;
+        case EPI_BIAS_F32: launch_gemm256_t<EPI_BIAS_F32>(e, p); break;
+        default: throw ArgError{"gemm256: unsupported epilogue", MOCR_ERR_ARG};
+    }
+}
+
+// A [M,K] (lda), W [N,K] (ldw=K), out (ldo).  tile: 64, 128, or 256 (= the 256x128 bf16 kernel).
+// split > 1 only with EPI_SLAB.
 template <typename T>
 void gemm(mocr_engine* e, const char* name, const void* A, int lda, const void* W, const float* bias, void* out, int ldo,
           const float* resid, int M, int N, int K, int epi, int tile, int split, long long slab_stride = 0,
           const float* pos = nullptr, int patches = 0) {
     const int kt = 128 / (int)sizeof(T);
-    if (N % tile || K % (kt * split) || (split > 1 && epi != EPI_SLAB))
+    if (N % (tile == 256 ? 128 : tile) || K % (kt * split) || (split > 1 && epi != EPI_SLAB) ||
+        (tile == 256 && (sizeof(T) != 2 || split != 1)))
         throw ArgError{std::string("gemm shape not tileable: ") + name, MOCR_ERR_ARG};
     GemmParams p{};
     p.A = A; p.W = W; p.bias = bias; p.out = out; p.resid = resid; p.pos = pos;
     p.M = M; p.N = N; p.lda = lda; p.ldw = K; p.ldo = ldo;
     p.k_per_split = K / split; p.slab_stride = slab_stride; p.patches = patches;
+    static const int ablate = env_int("MOCR_GEMM_ABLATE", 0);
+    p.ablate = ablate;
     const double out_b = (epi == EPI_BIAS || epi == EPI_BIAS_GELU) ? sizeof(T) : 4.0;
     const double bytes = ((double)M * K + (double)N * K) * sizeof(T) + (double)M * N * out_b * (epi == EPI_SLAB ? split : 1) +
                          (epi == EPI_BIAS_RESID ? (double)M * N * 4 : 0);
     ProfScope ps(e, name, 2.0 * M * N * K, bytes);
-    if (tile == 128) launch_gemm_epi<T, 128, 128>(e, p, epi, split);
+    if (tile == 256) launch_gemm256(e, p, epi);
+    else if (tile == 128) launch_gemm_epi<T, 128, 128>(e, p, epi, split);
     else if (tile == 64) launch_gemm_epi<T, 64, 64>(e, p, epi, split);
-    else throw ArgError{"gemm tile must be 64 or 128", MOCR_ERR_ARG};
+    else throw ArgError{"gemm tile must be 64, 128 or 256", MOCR_ERR_ARG};
 }
 
 // ---------------------------------------------------------------------------------------- encoder
@@ -287,33 +322,49 @@ void run_encoder(mocr_engine* e, const uint8_t* d_gray, int n) {
         hipLaunchKernelGGL(cls_rows_kernel, dim3((n * D + 255) / 256), dim3(256), 0, e->stream, w.cls, w.pos_enc, e->X, n, S, D);
         HIPCHECK(hipGetLastError());
     }
-    gemm<T>(e, "gemm_patch_embed", e->Hb, P * P, w.wpe, w.bpe, e->X, D, nullptr, MPATCH, D, P * P, EPI_PATCH, 128, 1, 0,
+    // big-tile kernel once there are enough 256-row tiles to fill the chip (bf16 only)
+    static const int enc_tile_env = env_int("MOCR_ENC_TILE", 0);
+    const int ET = enc_tile_env ? enc_tile_env : 128;
+    // measured (tools/gemm_bench.py): the 256x128 ring kernel wins only where N is large and the
+    // epilogue light (QKV); the short-K, fp32-residual GEMMs are better with two 128x128 blocks per
+    // CU overlapping each other's epilogue
+    const int ETQ = enc_tile_env ? enc_tile_env : ((sizeof(T) == 2 && M >= 256 * 48) ? 256 : 128);
+    gemm<T>(e, "gemm_patch_embed", e->Hb, P * P, w.wpe, w.bpe, e->X, D, nullptr, MPATCH, D, P * P, EPI_PATCH, ET, 1, 0,
             w.pos_enc, NP);
     const int impl = (e->cfg.flags & MOCR_FLAG_SIMPLE_ATTENTION) ? 0 : 1;
     for (int l = 0; l < e->cfg.enc_layers; ++l) {
         const EncLayerW& L = w.enc[l];
         layernorm<T>(e, e->X, L.ln1g, L.ln1b, e->Xn, M);
-        gemm<T>(e, "gemm_enc_qkv", e->Xn, D, L.wqkv, L.bqkv, e->QKV, 3 * D, nullptr, M, 3 * D, D, EPI_BIAS, 128, 1);
+        gemm<T>(e, "gemm_enc_qkv", e->Xn, D, L.wqkv, L.bqkv, e->QKV, 3 * D, nullptr, M, 3 * D, D, EPI_BIAS, ETQ, 1);
         enc_attention<T>(e, e->QKV, e->CTX, n, impl);
-        gemm<T>(e, "gemm_enc_oproj", e->CTX, D, L.wo, L.bo, e->X, D, e->X, M, D, D, EPI_BIAS_RESID, 128, 1);
+        gemm<T>(e, "gemm_enc_oproj", e->CTX, D, L.wo, L.bo, e->X, D, e->X, M, D, D, EPI_BIAS_RESID, ET, 1);
         layernorm<T>(e, e->X, L.ln2g, L.ln2b, e->Xn, M);
-        gemm<T>(e, "gemm_enc_fc1", e->Xn, D, L.w1, L.b1, e->Hb, F, nullptr, M, F, D, EPI_BIAS_GELU, 128, 1);
-        gemm<T>(e, "gemm_enc_fc2", e->Hb, F, L.w2, L.b2, e->X, D, e->X, M, D, F, EPI_BIAS_RESID, 128, 1);
+        gemm<T>(e, "gemm_enc_fc1", e->Xn, D, L.w1, L.b1, e->Hb, F, nullptr, M, F, D, EPI_BIAS_GELU, ET, 1);
+        gemm<T>(e, "gemm_enc_fc2", e->Hb, F, L.w2, L.b2, e->X, D, e->X, M, D, F, EPI_BIAS_RESID, ET, 1);
     }
     layernorm<T>(e, e->X, w.lnfg, w.lnfb, e->ENC, M);
 }
 
 // ---------------------------------------------------------------------------------------- decoder
+static int dec_tile(int rows) {
+    static const int forced = env_int("MOCR_DEC_TILE", 0);
+    static const int fat = env_int("MOCR_DEC_FAT_ROWS", 256);
+    if (forced) return forced;
+    return rows >= fat ? 128 : 64;
+}
+
 static int pick_split(int N, int K, int kt, int rows, long long slab_cap_per_row) {
-    // 64x64 output tiles; split K until ~150-200 blocks cover the chip, bounded by the K-tiles and
-    // by the slab buffer.  Every extra slab is an fp32 [rows,N] write plus a read by the consumer,
-    // so fat batches (many row tiles) split less.
-    const int tiles = (N / 64) * ((rows + 63) / 64);
+    // Split K until ~`target` blocks cover the chip, bounded by the K-tiles and by the slab buffer.
+    // Every extra slab is an fp32 [rows,N] write plus a read by the consumer, so fat batches
+    // (many row tiles) split less.
+    static const int target = env_int("MOCR_DEC_BLOCKS", 150);
+    const int tile = dec_tile(rows);
+    const int tiles = (N / tile) * ((rows + tile - 1) / tile);
     const int ktiles = K / kt;
     int split = 1;
-    while (tiles * split < 150 && split * 2 <= ktiles && ktiles % (split * 2) == 0 && (long long)(split * 2) * N <= slab_cap_per_row)
+    while (tiles * split < target && split * 2 <= ktiles && ktiles % (split * 2) == 0 && (long long)(split * 2) * N <= slab_cap_per_row)
         split *= 2;
-    if (tiles * split < 100 && ktiles % (split * 3) == 0 && (long long)(split * 3) * N <= slab_cap_per_row) split *= 3;
+    if (tiles * split * 3 <= target * 2 && ktiles % (split * 3) == 0 && (long long)(split * 3) * N <= slab_cap_per_row) split *= 3;
     return split;
 }
 
@@ -321,7 +372,7 @@ template <typename T>
 int dec_gemm(mocr_engine* e, const char* name, const void* A, int lda, const void* W, int N, int K, int rows) {
     const int kt = 128 / (int)sizeof(T);
     const int split = pick_split(N, K, kt, rows, e->slab_cap / e->Bp);
-    gemm<T>(e, name, A, lda, W, nullptr, e->slabs, N, nullptr, rows, N, K, EPI_SLAB, 64, split, (long long)e->Bp * N);
+    gemm<T>(e, name, A, lda, W, nullptr, e->slabs, N, nullptr, rows, N, K, EPI_SLAB, dec_tile(rows), split, (long long)e->Bp * N);
     return split;
 }
 
@@ -417,7 +468,7 @@ void decode_step(mocr_engine* e, const DecState& st, int n, int t) {
         ns = dec_gemm<T>(e, "gemm_dec_proj", e->ctx_t, D, L.woc, D, D, n);
         dec_add_ln<T>(e, ns, D, L.boc, e->a_f32, L.ln2g, L.ln2b, e->c_f32, e->c_t, n, false);
         if (pick_split(F, D, 128 / (int)sizeof(T), n, e->slab_cap / e->Bp) == 1) {
-            gemm<T>(e, "gemm_dec_fc1", e->c_t, D, L.w1, L.b1, e->h_t, F, nullptr, n, F, D, EPI_BIAS_GELU, 64, 1);
+            gemm<T>(e, "gemm_dec_fc1", e->c_t, D, L.w1, L.b1, e->h_t, F, nullptr, n, F, D, EPI_BIAS_GELU, dec_tile(n), 1);
         } else {
             ns = dec_gemm<T>(e, "gemm_dec_fc1", e->c_t, D, L.w1, F, D, n);
             ProfScope ps(e, "dec_bias_gelu", 0, (double)n * F * (4.0 * ns + sizeof(T)));
@@ -437,8 +488,11 @@ void decode_step(mocr_engine* e, const DecState& st, int n, int t) {
 
 template <typename T>
 void run_cross_kv(mocr_engine* e, int n) {
-    gemm<T>(e, "gemm_cross_kv", e->ENC, e->D, e->w.wckv, e->w.bckv, e->CKV, e->NCKV, nullptr, n * e->S, e->NCKV, e->D,
-            EPI_BIAS, 128, 1);
+    const int M = n * e->S;
+    static const int enc_tile_env = env_int("MOCR_ENC_TILE", 0);
+    const int ET = enc_tile_env ? enc_tile_env : ((sizeof(T) == 2 && M >= 256 * 48) ? 256 : 128);
+    gemm<T>(e, "gemm_cross_kv", e->ENC, e->D, e->w.wckv, e->w.bckv, e->CKV, e->NCKV, nullptr, M, e->NCKV, e->D,
+            EPI_BIAS, ET, 1);
 }
 
 // Raise the dynamic-LDS limit of every kernel that needs it (done once, outside any capture).
@@ -450,14 +504,20 @@ template <typename T> void init_kernel_attrs() {
     set_max_lds(gemm_kernel<T, 128, 128, EPI_BIAS_RESID>, l128);
     set_max_lds(gemm_kernel<T, 128, 128, EPI_PATCH>, l128);
     set_max_lds(gemm_kernel<T, 128, 128, EPI_BIAS_F32>, l128);
-    set_max_lds(gemm_kernel<T, 64, 64, EPI_SLAB>, l64);
-    set_max_lds(gemm_kernel<T, 64, 64, EPI_BIAS>, l64);
-    set_max_lds(gemm_kernel<T, 64, 64, EPI_BIAS_GELU>, l64);
-    set_max_lds(gemm_kernel<T, 64, 64, EPI_BIAS_RESID>, l64);
-    set_max_lds(gemm_kernel<T, 64, 64, EPI_PATCH>, l64);
-    set_max_lds(gemm_kernel<T, 64, 64, EPI_BIAS_F32>, l64);
+    set_max_lds(gemm_kernel<T, 64, 64, EPI_SLAB, 2>, l64);
+    set_max_lds(gemm_kernel<T, 64, 64, EPI_BIAS, 2>, l64);
+    set_max_lds(gemm_kernel<T, 64, 64, EPI_BIAS_GELU, 2>, l64);
+    set_max_lds(gemm_kernel<T, 64, 64, EPI_BIAS_RESID, 2>, l64);
+    set_max_lds(gemm_kernel<T, 64, 64, EPI_PATCH, 2>, l64);
+    set_max_lds(gemm_kernel<T, 64, 64, EPI_BIAS_F32, 2>, l64);
     set_max_lds(enc_attn_simple_kernel<T>, (200 * 65 + 200 * 64 + 4 * 64 + 4 * 256) * 4);
     set_max_lds(enc_attn_mfma_kernel, ENC_SP * 128 + 64 * ENC_VT_LD * 2);
+    constexpr int l256 = 3 * (256 + 128) * 128;
+    set_max_lds(gemm256_kernel<EPI_BIAS>, l256);
+    set_max_lds(gemm256_kernel<EPI_BIAS_GELU>, l256);
+    set_max_lds(gemm256_kernel<EPI_BIAS_RESID>, l256);
+    set_max_lds(gemm256_kernel<EPI_PATCH>, l256);
+    set_max_lds(gemm256_kernel<EPI_BIAS_F32>, l256);
 }
 
 // `steps` consecutive greedy steps captured once and replayed: every per-step value (position,
@@ -787,7 +847,7 @@ void compute_geometry(mocr_engine* e) {
     e->D = c.hidden; e->H = c.heads; e->F = c.ffn; e->V = c.vocab;
     e->esz = c.dtype == MOCR_BF16 ? 2 : 4;
     e->Bp = round_up(c.max_batch, 128);
-    e->Mp = round_up(c.max_batch * e->S, 128) + 128;
+    e->Mp = round_up(c.max_batch * e->S, 256) + 256;
     e->NCKV = c.dec_layers * 2 * c.hidden;
 }
 

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(D / 4) void dec_add_ln_kernel(const float* __restri
     }
     if (GELU) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+        for (int e = 0; e < 4; ++e) v[e] = gelu_for<T>(v[e]);
     }
     v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
     float sm = wave_sum((v[0] + v[1]) + (v[2] + v[3]));
@@ -86,7 +86,7 @@ __global__ void dec_bias_gelu_kernel(const float* __restrict__ slabs, int nslab,
         const float4 x0 = *reinterpret_cast<const float4*>(slabs + (size_t)s * slab_stride + i);
         a0.x += x0.x; a0.y += x0.y; a0.z += x0.z; a0.w += x0.w;
     }
-    float o[4] = {gelu_erf(a0.x + a1.x), gelu_erf(a0.y + a1.y), gelu_erf(a0.z + a1.z), gelu_erf(a0.w + a1.w)};
+    float o[4] = {gelu_for<T>(a0.x + a1.x), gelu_for<T>(a0.y + a1.y), gelu_for<T>(a0.z + a1.z), gelu_for<T>(a0.w + a1.w)};
     elem<T>::st4(out + i, o);
 }
 

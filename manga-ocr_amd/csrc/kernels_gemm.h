@@ -44,13 +44,74 @@ struct GemmParams {
     long long slab_stride; // EPI_SLAB: elements between slabs
     int ntn;               // tiles along N
     int patches;           // EPI_PATCH: patches per image (196)
+    int ablate;            // diagnostics only (MOCR_GEMM_ABLATE): 1 no MFMA, 2 no DMA after tile 0, 4 no epilogue
 };
 
-template <typename T, int BM, int BN, int EPI>
+// Read the fp32 tile back from LDS row by row and apply the fused epilogue; every global access is
+// a 16-byte, row-contiguous access.  NT = threads in the block.
+template <typename T, int BM, int BN, int EPI, int NT>
+__device__ __forceinline__ void gemm_epilogue(const float* sC, const GemmParams& p, int m0, int n0, int tid, int z) {
+    constexpr int TPR = BN / 4;      // threads per output row (4 columns each)
+    constexpr int RPI = NT / TPR;    // rows per pass
+    const int col = (tid % TPR) * 4;
+    const int n = n0 + col;
+    float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (EPI != EPI_SLAB) {
+        const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+        bias4[0] = bv.x; bias4[1] = bv.y; bias4[2] = bv.z; bias4[3] = bv.w;
+    }
+#pragma unroll 4
+    for (int it = 0; it < BM / RPI; ++it) {
+        const int row = it * RPI + tid / TPR;
+        const int m = m0 + row;
+        if (m >= p.M) continue;
+        const float4 cv = *reinterpret_cast<const float4*>(&sC[row * BN + col]);
+        float v[4] = {cv.x + bias4[0], cv.y + bias4[1], cv.z + bias4[2], cv.w + bias4[3]};
+        if constexpr (EPI == EPI_SLAB) {
+            float* o = reinterpret_cast<float*>(p.out) + (size_t)z * p.slab_stride + (size_t)m * p.ldo + n;
+            *reinterpret_cast<float4*>(o) = cv;
+        } else if constexpr (EPI == EPI_BIAS) {
+            elem<T>::st4(reinterpret_cast<T*>(p.out) + (size_t)m * p.ldo + n, v);
+        } else if constexpr (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_for<T>(v[e]);
+            elem<T>::st4(reinterpret_cast<T*>(p.out) + (size_t)m * p.ldo + n, v);
+        } else if constexpr (EPI == EPI_BIAS_RESID) {
+            const float4 rv = *reinterpret_cast<const float4*>(p.resid + (size_t)m * p.ldo + n);
+            float* o = reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n;
+            *reinterpret_cast<float4*>(o) = make_float4(v[0] + rv.x, v[1] + rv.y, v[2] + rv.z, v[3] + rv.w);
+        } else if constexpr (EPI == EPI_PATCH) {
+            const int b = m / p.patches, pi = m - b * p.patches;
+            const float4 pv = *reinterpret_cast<const float4*>(p.pos + (size_t)(1 + pi) * p.N + n);
+            float* o = reinterpret_cast<float*>(p.out) + ((size_t)b * (p.patches + 1) + 1 + pi) * p.ldo + n;
+            *reinterpret_cast<float4*>(o) = make_float4(v[0] + pv.x, v[1] + pv.y, v[2] + pv.z, v[3] + pv.w);
+        } else {  // EPI_BIAS_F32
+            float* o = reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n;
+            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+// s_waitcnt vmcnt(N) needs an immediate: N = DMA instructions that may stay in flight
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N == 0 || N == 4 || N == 8 || N == 12 || N == 16 || N == 24, "add the count");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+}
+
+// NST = depth of the LDS ring: K-tile t+NST-1 is issued while K-tile t is multiplied.  NST = 2 is
+// the plain double buffer; the latency-bound skinny GEMMs of the decode step use NST = 4 (64x64
+// tile: 4 x 16 KiB) so a DMA has three K-tiles of time to land.
+template <typename T, int BM, int BN, int EPI, int NST = 2>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     constexpr int TM = BM / 64, TN = BN / 64;          // 32x32 MFMA tiles per wave
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
-    static_assert(BM * BN * 4 <= 2 * STAGE, "fp32 epilogue tile must fit the staging buffers");
+    constexpr int LPT = (BM / 8 + BN / 8) / 4;         // DMA instructions per wave per K-tile
+    static_assert(BM * BN * 4 <= NST * STAGE, "fp32 epilogue tile must fit the staging buffers");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -106,14 +167,26 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) { rowB[j] = wn * (BN / 2) + j * 32 + r32; swB[j] = (rowB[j] >> 1) & 7; }
 
-    stage(0, 0);
+#pragma unroll
+    for (int i = 0; i < NST - 1; ++i)
+        if (i < nt) stage(i, i);
     for (int t = 0; t < nt; ++t) {
-        // tile t has landed (each wave drains its own DMA, the barrier covers the others') and
-        // every wave has finished reading the buffer tile t+1 is about to overwrite
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (t + 1 < nt) stage(t + 1, (t + 1) & 1);
-        const char* sa = smem + (t & 1) * STAGE;
+        // tile t has landed: each wave waits for its own DMA, allowing the min(NST-2, nt-1-t) newer
+        // tiles to stay in flight; the raw barrier (no vmcnt drain) covers the other waves' pieces
+        // and tells that everyone has finished reading the slot tile t+NST-1 is about to overwrite
+        const int newer = nt - 1 - t;
+        if constexpr (NST == 2) {
+            wait_vmcnt<0>();
+        } else if constexpr (NST == 3) {
+            if (newer >= 1) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+        } else {
+            static_assert(NST == 4, "ring depth");
+            if (newer >= 2) wait_vmcnt<2 * LPT>(); else if (newer == 1) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + NST - 1 < nt) stage(t + NST - 1, (t + NST - 1) % NST);
+        const char* sa = smem + (t % NST) * STAGE;
         const char* sb = sa + A_BYTES;
         if constexpr (sizeof(T) == 2) {
 #pragma unroll
@@ -165,43 +238,137 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
             }
     __syncthreads();
 
-    constexpr int TPR = BN / 4;      // threads per output row (4 columns each)
-    constexpr int RPI = 256 / TPR;   // rows per pass
-    const int col = (tid % TPR) * 4;
-    const int n = n0 + col;
-    float bias4[4] = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (EPI != EPI_SLAB) {
-        const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
-        bias4[0] = bv.x; bias4[1] = bv.y; bias4[2] = bv.z; bias4[3] = bv.w;
+    gemm_epilogue<T, BM, BN, EPI, 256>(sC, p, m0, n0, tid, blockIdx.z);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Big-tile bf16 GEMM for the encoder (M = rows*197 is large): 256 x 128 output tile, BK = 64.
+//   * 4 waves as 2(M) x 2(N), ONE wave per SIMD, each owning 128 x 64 = 4 x 2 MFMA 32x32 tiles
+//     (128 accumulator registers).  Per 16-deep k-step a wave reads 4 A + 2 B fragments for 8
+//     MFMAs: 0.75 ds_read_b128 per MFMA instead of 1.0 for the 64x64 wave tile of gemm_kernel,
+//     which keeps the LDS read port (256 B/clk/CU) well below saturation.
+//   * 3-stage LDS ring (3 x 48 KiB = 144 KiB, one block per CU), filled by global_load_lds;
+//     K-tile t+2 is issued while K-tile t is multiplied, so a DMA has two full K-tiles (~2000
+//     cycles) to land.  Each wave waits for its own pieces with a COUNTED s_waitcnt vmcnt(12)
+//     (12 = DMA instructions a wave issues per K-tile: the newest tile stays in flight) and the
+//     block meets at ONE raw s_barrier per K-tile (a __syncthreads() would drain vmcnt to 0).
+//   * same source-side XOR swizzle, XCD-aware block remap and LDS-staged fused epilogue as
+//     gemm_kernel (cdna_hip_programming.md §5: "Pipelining across barriers", rule 21, T1).
+// ------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(256, 1) void gemm256_kernel(GemmParams p) {
+    using T = bf16_t;
+    constexpr int BM = 256, BN = 128, NST = 3;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;   // 48 KiB
+    constexpr int LPT = (BM / 8 + BN / 8) / 4;                                         // 12 DMA / wave / K-tile
+    static_assert(BM * BN * 4 <= NST * STAGE, "fp32 epilogue tile must fit the ring");
+    static_assert(LPT == 12, "the counted wait below is written for 12");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r32 = lane & 31, hh = lane >> 5;
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-#pragma unroll 4
-    for (int it = 0; it < BM / RPI; ++it) {
-        const int row = it * RPI + tid / TPR;
-        const int m = m0 + row;
-        if (m >= p.M) continue;
-        const float4 cv = *reinterpret_cast<const float4*>(&sC[row * BN + col]);
-        float v[4] = {cv.x + bias4[0], cv.y + bias4[1], cv.z + bias4[2], cv.w + bias4[3]};
-        if constexpr (EPI == EPI_SLAB) {
-            float* o = reinterpret_cast<float*>(p.out) + (size_t)blockIdx.z * p.slab_stride + (size_t)m * p.ldo + n;
-            *reinterpret_cast<float4*>(o) = cv;
-        } else if constexpr (EPI == EPI_BIAS) {
-            elem<T>::st4(reinterpret_cast<T*>(p.out) + (size_t)m * p.ldo + n, v);
-        } else if constexpr (EPI == EPI_BIAS_GELU) {
+    const int tn = bid % p.ntn, tm = bid / p.ntn;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int nt = p.k_per_split / 64;
+    const char* Ab = (const char*)p.A + (size_t)m0 * p.lda * 2;
+    const char* Wb = (const char*)p.W + (size_t)n0 * p.ldw * 2;
+    const size_t a_row = (size_t)p.lda * 2, w_row = (size_t)p.ldw * 2;
+    const int prow = lane >> 3, pchunk = lane & 7;
+
+    auto stage = [&](int t, int buf) {
+        char* sa = smem + buf * STAGE;
+        char* sb = sa + A_BYTES;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-            elem<T>::st4(reinterpret_cast<T*>(p.out) + (size_t)m * p.ldo + n, v);
-        } else if constexpr (EPI == EPI_BIAS_RESID) {
-            const float4 rv = *reinterpret_cast<const float4*>(p.resid + (size_t)m * p.ldo + n);
-            float* o = reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n;
-            *reinterpret_cast<float4*>(o) = make_float4(v[0] + rv.x, v[1] + rv.y, v[2] + rv.z, v[3] + rv.w);
-        } else if constexpr (EPI == EPI_PATCH) {
-            const int b = m / p.patches, pi = m - b * p.patches;
-            const float4 pv = *reinterpret_cast<const float4*>(p.pos + (size_t)(1 + pi) * p.N + n);
-            float* o = reinterpret_cast<float*>(p.out) + ((size_t)b * (p.patches + 1) + 1 + pi) * p.ldo + n;
-            *reinterpret_cast<float4*>(o) = make_float4(v[0] + pv.x, v[1] + pv.y, v[2] + pv.z, v[3] + pv.w);
-        } else {  // EPI_BIAS_F32
-            float* o = reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n;
-            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+        for (int i = 0; i < BM / 32; ++i) {
+            const int pc = wave + 4 * i;
+            const int row = pc * 8 + prow;
+            const int c = pchunk ^ ((row >> 1) & 7);
+            glds16(Ab + (size_t)row * a_row + (size_t)t * 128 + c * 16, sa + pc * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < BN / 32; ++i) {
+            const int pc = wave + 4 * i;
+            const int row = pc * 8 + prow;
+            const int c = pchunk ^ ((row >> 1) & 7);
+            glds16(Wb + (size_t)row * w_row + (size_t)t * 128 + c * 16, sb + pc * 1024);
+        }
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    int offA[4], offB[2], swA[4], swB[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int row = wm * 128 + i * 32 + r32; offA[i] = row * 128; swA[i] = (row >> 1) & 7; }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { const int row = wn * 64 + j * 32 + r32; offB[j] = A_BYTES + row * 128; swB[j] = (row >> 1) & 7; }
+
+    stage(0, 0);
+    if (nt > 1) stage(1, 1);
+    for (int t = 0; t < nt; ++t) {
+        // tile t landed: only the newest tile (if any) may still be in flight
+        if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // every wave is past its reads of tile t-1, so its ring slot can be refilled with tile t+2
+        if (t + 2 < nt && !(p.ablate & 2)) stage(t + 2, (t + 2) % NST);
+        const char* sbuf = smem + (t % NST) * STAGE;
+        // software-pipelined fragments: k-step s+1 is read from LDS while k-step s is multiplied
+        // (two register sets), so the wait in front of each MFMA group is a counted lgkmcnt
+        bf16x8 fa[2][4], fb[2][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[0][i] = *(const bf16x8*)(sbuf + offA[i] + ((hh ^ swA[i]) << 4));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[0][j] = *(const bf16x8*)(sbuf + offB[j] + ((hh ^ swB[j]) << 4));
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (s < 3) {
+                const int c = 2 * (s + 1) + hh;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fa[(s + 1) & 1][i] = *(const bf16x8*)(sbuf + offA[i] + ((c ^ swA[i]) << 4));
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fb[(s + 1) & 1][j] = *(const bf16x8*)(sbuf + offB[j] + ((c ^ swB[j]) << 4));
+            }
+            __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ahead of this step's MFMAs
+            if (!(p.ablate & 1)) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s & 1][i], fb[s & 1][j], acc[i][j], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(fa[s & 1][i]));
+#pragma unroll
+                for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(fb[s & 1][j]));
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
+    __syncthreads();
+    float* sC = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const int col = wn * 64 + j * 32 + r32;
+                sC[row * BN + col] = acc[i][j][r];
+            }
+    __syncthreads();
+    if (!(p.ablate & 4)) gemm_epilogue<T, BM, BN, EPI, 256>(sC, p, m0, n0, tid, 0);
 }

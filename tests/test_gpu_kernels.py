@@ -57,6 +57,37 @@ def test_gemm_epilogues(dtype, tile, M, N, K, epi):
     assert err <= tol
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (512, 768, 768), (700, 2304, 768), (1000, 768, 3072), (256, 768, 256)])
+@pytest.mark.parametrize("epi", [EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_BIAS_F32])
+def test_gemm_256x128_three_stage_ring(M, N, K, epi):
+    """The big-tile encoder kernel (bf16 only): K from 1 to 48 K-tiles exercises the ring's
+    prologue, steady state (counted vmcnt) and drain; M not a multiple of 256 exercises the
+    row guard."""
+    eng = engine("bf16")
+    rs = np.random.RandomState(M + N + K + epi)
+    Mp = (M + 255) // 256 * 256
+    A = bf16_round(rs.standard_normal((Mp, K)).astype(np.float32))
+    W = bf16_round((rs.standard_normal((N, K)) * 0.05).astype(np.float32))
+    bias = rs.standard_normal(N).astype(np.float32)
+    resid = rs.standard_normal((M, N)).astype(np.float32)
+    ref = A[:M].astype(np.float64) @ W.astype(np.float64).T + bias
+    if epi == EPI_BIAS_GELU:
+        ref = _gelu(ref)
+    if epi == EPI_BIAS_RESID:
+        ref = ref + resid
+    out_f32 = epi in (EPI_BIAS_RESID, EPI_BIAS_F32)
+    dO = torch.full((M, N), float("nan"), device="cuda", dtype=torch.float32 if out_f32 else torch.bfloat16)
+    dR = torch.from_numpy(resid).cuda() if epi == EPI_BIAS_RESID else None
+    dA, dW, dB = _dev(A, "bf16"), _dev(W, "bf16"), torch.from_numpy(bias).cuda()
+    torch.cuda.synchronize()
+    eng.op_gemm(dA, dW, dB, dO, dR, M, N, K, epi, tile=256, split_k=1)
+    got = dO.float().cpu().numpy().astype(np.float64)
+    err = np.abs(got - ref).max() / np.abs(ref).max()
+    tol = 1e-5 if out_f32 else 6e-3
+    report(f"gemm256 M{M} N{N} K{K} epi{epi}: max rel err {err:.3e} (tol {tol:.1e})")
+    assert np.isfinite(got).all() and err <= tol
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("M,N,K,split", [(64, 768, 768, 12), (37, 2304, 768, 4), (128, 768, 3072, 16), (64, 6144, 768, 2)])
 def test_gemm_split_k_slabs(dtype, M, N, K, split):

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""GPU micro-benchmark of the GEMM kernel through the C ABI (mocr_op_gemm + HIP-event profile).
+    python tools/gemm_bench.py            # a table of the recogniser's GEMM shapes
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "manga-ocr_amd")]
+import numpy as np  # noqa: E402,F401
+import torch  # noqa: E402
+
+from manga_ocr.engine import Engine  # noqa: E402
+from manga_ocr.weights import DEFAULT_SPEC, synthetic_weights  # noqa: E402
+
+EPI = {"slab": 0, "bias": 1, "gelu": 2, "resid": 3, "f32": 5}
+
+SHAPES = [  # (name, M, N, K, epi, tile, split)
+    ("enc_qkv", 100864, 2304, 768, "bias", 128, 1), ("enc_oproj", 100864, 768, 768, "resid", 128, 1),
+    ("enc_fc1", 100864, 3072, 768, "gelu", 128, 1), ("enc_fc1_nogelu", 100864, 3072, 768, "bias", 128, 1),
+    ("enc_fc2", 100864, 768, 3072, "resid", 128, 1),
+    ("enc_qkv 256", 100864, 2304, 768, "bias", 256, 1), ("enc_oproj 256", 100864, 768, 768, "resid", 256, 1),
+    ("enc_fc1 256", 100864, 3072, 768, "gelu", 256, 1), ("enc_fc2 256", 100864, 768, 3072, "resid", 256, 1),
+    ("enc_ckv 256", 100864, 3072, 768, "bias", 256, 1), ("enc_fc2 256 b256", 50432, 768, 3072, "resid", 256, 1),
+    ("dec_proj t64 s2", 512, 768, 768, "slab", 64, 2), ("dec_proj t64 s12", 512, 768, 768, "slab", 64, 12),
+    ("dec_proj t128 s4", 512, 768, 768, "slab", 128, 4), ("dec_proj t128 s12", 512, 768, 768, "slab", 128, 12),
+    ("dec_proj t64 s1 bias", 512, 768, 768, "bias", 64, 1),
+    ("dec_fc1 t64 gelu", 512, 3072, 768, "gelu", 64, 1), ("dec_fc1 t128 gelu", 512, 3072, 768, "gelu", 128, 1),
+    ("dec_fc2 t64 s4", 512, 768, 3072, "slab", 64, 4), ("dec_fc2 t64 s16", 512, 768, 3072, "slab", 64, 16),
+    ("dec_fc2 t128 s8", 512, 768, 3072, "slab", 128, 8),
+    ("dec_vocab t64 s1", 512, 6144, 768, "slab", 64, 1), ("dec_vocab t128 s1", 512, 6144, 768, "slab", 128, 1),
+    ("dec_vocab t128 s2", 512, 6144, 768, "slab", 128, 2),
+    ("dec_proj64 t64 s12", 64, 768, 768, "slab", 64, 12), ("dec_vocab64 t64 s2", 64, 6144, 768, "slab", 64, 2),
+]
+
+
+def main():
+    eng = Engine(synthetic_weights(0), DEFAULT_SPEC, dtype="bf16", max_batch=8)
+    for name, M, N, K, epi, tile, split in SHAPES:
+        Mp = (M + 255) // 256 * 256
+        A = (torch.randn(Mp, K, device="cuda") * 0.5).to(torch.bfloat16)
+        W = (torch.randn(N, K, device="cuda") * 0.05).to(torch.bfloat16)
+        bias = torch.randn(N, device="cuda")
+        out_f32 = epi in ("slab", "resid", "f32")
+        out = torch.zeros((split if epi == "slab" else 1) * M, N, device="cuda", dtype=torch.float32 if out_f32 else torch.bfloat16)
+        resid = torch.randn(M, N, device="cuda") if epi == "resid" else None
+        torch.cuda.synchronize()
+        for _ in range(3):
+            eng.op_gemm(A, W, bias, out, resid, M, N, K, EPI[epi], tile=tile, split_k=split)
+        eng.profile_enable(True)
+        eng.profile_reset()
+        for _ in range(20):
+            eng.op_gemm(A, W, bias, out, resid, M, N, K, EPI[epi], tile=tile, split_k=split)
+        st = eng.profile_get()[0]
+        eng.profile_enable(False)
+        us = st["total_ms"] / st["launches"] * 1e3
+        print(f"{name:22s} M{M:7d} N{N:5d} K{K:5d} {epi:5s} tile{tile:4d} split{split:3d}: {us:9.1f} us  {2.0 * M * N * K / us / 1e6:8.1f} TFLOP/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()
