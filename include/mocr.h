@@ -47,7 +47,8 @@ enum { MOCR_F32 = 0, MOCR_BF16 = 1 };
 enum {
     MOCR_FLAG_SIMPLE_ATTENTION = 1 << 0, /* encoder attention on the VALU kernel even in bf16 mode */
     MOCR_FLAG_NO_GRAPH = 1 << 1,         /* launch decode steps eagerly instead of replaying a HIP graph */
-    MOCR_FLAG_NO_EARLY_EXIT = 1 << 2     /* always run max_len-1 decode steps */
+    MOCR_FLAG_NO_EARLY_EXIT = 1 << 2,    /* always run max_len-1 decode steps */
+    MOCR_FLAG_CLASSIC_ATTENTION = 1 << 3 /* bf16: projected K/V caches instead of the latent (absorbed) decode attention */
 };
 
 typedef struct mocr_engine mocr_engine;
@@ -130,6 +131,10 @@ int mocr_op_gemm(mocr_engine* e, const void* dA, const void* dW, const float* d_
 int mocr_op_layernorm(mocr_engine* e, const float* d_x, const float* d_gamma, const float* d_beta,
                       void* d_out, int32_t M);
 int mocr_op_enc_attention(mocr_engine* e, const void* d_qkv, void* d_ctx, int32_t n, int32_t impl);
+/* Latent decode attention (bf16 engines): d_qt [n,16,768], keys d_x with x_batch_stride elements between
+ * sequences, context length len for every row; d_out [n,16,768] = softmax(qt . x^T) x per head. */
+int mocr_op_latent_attention(mocr_engine* e, const void* d_qt, const void* d_x, void* d_out, int32_t n, int32_t len,
+                             int64_t x_batch_stride);
 
 /* ---- per-kernel timing (HIP events on the engine's stream) -------------------------------- */
 typedef struct mocr_kernel_stat {

@@ -28,6 +28,7 @@
 #include "kernels_attn.h"
 #include "kernels_decode.h"
 #include "kernels_gemm.h"
+#include "kernels_latent.h"
 #include "kernels_misc.h"
 
 namespace {
@@ -55,6 +56,7 @@ struct EncLayerW {
 };
 struct DecLayerW {
     void *wqkv, *wo, *wqc, *woc, *w1, *w2;
+    void *wkT_s = nullptr, *wkT_c = nullptr;   // latent attention: (Wk^T)/8 of the self / cross attention, [768 in][768 out]
     float *bqkv, *bo, *bqc, *boc, *b1, *b2, *ln1g, *ln1b, *ln2g, *ln2b, *ln3g, *ln3b;
 };
 struct Weights {
@@ -67,6 +69,7 @@ struct Weights {
     void* wt = nullptr; float *bt = nullptr, *lntg = nullptr, *lntb = nullptr;
     void* wv = nullptr; float* bv = nullptr;
     float* lut = nullptr;
+    float* zero_bias = nullptr;
 };
 
 struct ProfRec { int kid; hipEvent_t e0, e1; double flops, bytes; };
@@ -92,6 +95,8 @@ struct LaneCtx {
     int *ids = nullptr, *step = nullptr, *finished = nullptr, *len = nullptr, *n_unf = nullptr;
     int* forced = nullptr; float* logits_dbg = nullptr; size_t forced_cap = 0, logits_cap = 0;
     int* h_pinned = nullptr;                        // [4] pinned: early-exit flags
+    // latent attention (bf16): q [Bp,768], Qt / Et [Bp,16,768], per-layer input rows [layers][Bp][max_len][768]
+    void *q_t = nullptr, *qt = nullptr, *et = nullptr, *xcache = nullptr;
 };
 
 // One recognise request of <= max_batch crops.
@@ -121,6 +126,7 @@ struct mocr_engine : LaneCtx {
     std::string err;
     std::mutex mu;
     bool committed = false;
+    bool latent = false;            // bf16 engines: latent (absorbed) decode attention
     std::map<std::string, std::vector<float>> host_w;
     std::map<std::string, std::vector<int64_t>> host_shape;
     std::vector<void*> allocs;
@@ -207,26 +213,26 @@ template <typename K> void set_max_lds(K kernel, int bytes) {
 template <int BM> constexpr int gemm_ring() { return 2; }   // LDS ring depth per tile size
 
 template <typename T, int BM, int BN, int EPI>
-void launch_gemm_t(mocr_engine* e, const GemmParams& p0, int split) {
+void launch_gemm_t(mocr_engine* e, const GemmParams& p0, int split, int ybatch) {
     GemmParams p = p0;
     p.ntn = p.N / BN;
     const int ntm = (p.M + BM - 1) / BM;
     constexpr int NST = gemm_ring<BM>();
     constexpr int lds = NST * (BM + BN) * 128;
-    dim3 grid(ntm * p.ntn, 1, split);
+    dim3 grid(ntm * p.ntn, ybatch, split);
     hipLaunchKernelGGL((gemm_kernel<T, BM, BN, EPI, NST>), grid, dim3(256), lds, e->stream, p);
     HIPCHECK(hipGetLastError());
 }
 
 template <typename T, int BM, int BN>
-void launch_gemm_epi(mocr_engine* e, const GemmParams& p, int epi, int split) {
+void launch_gemm_epi(mocr_engine* e, const GemmParams& p, int epi, int split, int ybatch = 1) {
     switch (epi) {
-        case EPI_SLAB: launch_gemm_t<T, BM, BN, EPI_SLAB>(e, p, split); break;
-        case EPI_BIAS: launch_gemm_t<T, BM, BN, EPI_BIAS>(e, p, split); break;
-        case EPI_BIAS_GELU: launch_gemm_t<T, BM, BN, EPI_BIAS_GELU>(e, p, split); break;
-        case EPI_BIAS_RESID: launch_gemm_t<T, BM, BN, EPI_BIAS_RESID>(e, p, split); break;
-        case EPI_PATCH: launch_gemm_t<T, BM, BN, EPI_PATCH>(e, p, split); break;
-        case EPI_BIAS_F32: launch_gemm_t<T, BM, BN, EPI_BIAS_F32>(e, p, split); break;
+        case EPI_SLAB: launch_gemm_t<T, BM, BN, EPI_SLAB>(e, p, split, ybatch); break;
+        case EPI_BIAS: launch_gemm_t<T, BM, BN, EPI_BIAS>(e, p, split, ybatch); break;
+        case EPI_BIAS_GELU: launch_gemm_t<T, BM, BN, EPI_BIAS_GELU>(e, p, split, ybatch); break;
+        case EPI_BIAS_RESID: launch_gemm_t<T, BM, BN, EPI_BIAS_RESID>(e, p, split, ybatch); break;
+        case EPI_PATCH: launch_gemm_t<T, BM, BN, EPI_PATCH>(e, p, split, ybatch); break;
+        case EPI_BIAS_F32: launch_gemm_t<T, BM, BN, EPI_BIAS_F32>(e, p, split, ybatch); break;
         default: throw ArgError{"unknown GEMM epilogue", MOCR_ERR_ARG};
     }
 }
@@ -253,10 +259,12 @@ void launch_gemm256(mocr_engine* e, const GemmParams& p, int epi) {
 
 // A [M,K] (lda), W [N,K] (ldw=K), out (ldo).  tile: 64, 128, or 256 (= the 256x128 bf16 kernel).
 // split > 1 only with EPI_SLAB.
+struct HeadBatch { int heads = 1; long long a_yoff = 0, w_yoff = 0, o_yoff = 0, b_yoff = 0; int ldw = 0; };
+
 template <typename T>
 void gemm(mocr_engine* e, const char* name, const void* A, int lda, const void* W, const float* bias, void* out, int ldo,
           const float* resid, int M, int N, int K, int epi, int tile, int split, long long slab_stride = 0,
-          const float* pos = nullptr, int patches = 0) {
+          const float* pos = nullptr, int patches = 0, const HeadBatch* hb = nullptr) {
     const int kt = 128 / (int)sizeof(T);
     if (N % (tile == 256 ? 128 : tile) || K % (kt * split) || (split > 1 && epi != EPI_SLAB) ||
         (tile == 256 && (sizeof(T) != 2 || split != 1)))
@@ -264,16 +272,22 @@ void gemm(mocr_engine* e, const char* name, const void* A, int lda, const void* 
     GemmParams p{};
     p.A = A; p.W = W; p.bias = bias; p.out = out; p.resid = resid; p.pos = pos;
     p.M = M; p.N = N; p.lda = lda; p.ldw = K; p.ldo = ldo;
+    int ybatch = 1;
+    if (hb) {
+        if (epi != EPI_BIAS || tile == 256) throw ArgError{"per-head batched GEMM needs EPI_BIAS on the 64/128 kernel", MOCR_ERR_ARG};
+        ybatch = hb->heads; p.a_yoff = hb->a_yoff; p.w_yoff = hb->w_yoff; p.o_yoff = hb->o_yoff; p.b_yoff = hb->b_yoff;
+        if (hb->ldw) p.ldw = hb->ldw;
+    }
     p.k_per_split = K / split; p.slab_stride = slab_stride; p.patches = patches;
     static const int ablate = env_int("MOCR_GEMM_ABLATE", 0);
     p.ablate = ablate;
     const double out_b = (epi == EPI_BIAS || epi == EPI_BIAS_GELU) ? sizeof(T) : 4.0;
     const double bytes = ((double)M * K + (double)N * K) * sizeof(T) + (double)M * N * out_b * (epi == EPI_SLAB ? split : 1) +
                          (epi == EPI_BIAS_RESID ? (double)M * N * 4 : 0);
-    ProfScope ps(e, name, 2.0 * M * N * K, bytes);
+    ProfScope ps(e, name, 2.0 * M * N * K * ybatch, bytes * ybatch);
     if (tile == 256) launch_gemm256(e, p, epi);
-    else if (tile == 128) launch_gemm_epi<T, 128, 128>(e, p, epi, split);
-    else if (tile == 64) launch_gemm_epi<T, 64, 64>(e, p, epi, split);
+    else if (tile == 128) launch_gemm_epi<T, 128, 128>(e, p, epi, split, ybatch);
+    else if (tile == 64) launch_gemm_epi<T, 64, 64>(e, p, epi, split, ybatch);
     else throw ArgError{"gemm tile must be 64, 128 or 256", MOCR_ERR_ARG};
 }
 
@@ -378,14 +392,19 @@ int dec_gemm(mocr_engine* e, const char* name, const void* A, int lda, const voi
 
 template <typename T>
 void dec_add_ln(mocr_engine* e, int nslab, int N, const float* bias, const float* resid, const float* g, const float* b,
-                float* out_f32, void* out_t, int rows, bool gelu) {
+                float* out_f32, void* out_t, int rows, bool gelu, int cache_layer = -1) {
     ProfScope ps(e, "dec_add_ln", 0, (double)rows * N * 4 * (nslab + 3));
+    T* cache = nullptr;
+    const long long cstride = (long long)e->cfg.max_len * e->D;
+    if (cache_layer >= 0) cache = reinterpret_cast<T*>(e->xcache) + (size_t)cache_layer * e->Bp * cstride;
     if (gelu)
         hipLaunchKernelGGL((dec_add_ln_kernel<T, 768, true>), dim3(rows), dim3(192), 0, e->stream, e->slabs, nslab,
-                           (long long)e->Bp * N, bias, resid, g, b, out_f32, reinterpret_cast<T*>(out_t), rows, e->cfg.ln_eps);
+                           (long long)e->Bp * N, bias, resid, g, b, out_f32, reinterpret_cast<T*>(out_t), rows, e->cfg.ln_eps,
+                           cache, cstride, (const int*)e->step);
     else
         hipLaunchKernelGGL((dec_add_ln_kernel<T, 768, false>), dim3(rows), dim3(192), 0, e->stream, e->slabs, nslab,
-                           (long long)e->Bp * N, bias, resid, g, b, out_f32, reinterpret_cast<T*>(out_t), rows, e->cfg.ln_eps);
+                           (long long)e->Bp * N, bias, resid, g, b, out_f32, reinterpret_cast<T*>(out_t), rows, e->cfg.ln_eps,
+                           cache, cstride, (const int*)e->step);
     HIPCHECK(hipGetLastError());
 }
 
@@ -404,7 +423,8 @@ void dec_token(mocr_engine* e, const DecState& st, int nslab, int n) {
     ProfScope ps(e, FIRST ? "dec_token_first" : "dec_token", 0, FIRST ? 0.0 : (double)n * e->V * 4 * nslab);
     hipLaunchKernelGGL((dec_token_kernel<T, 768, FIRST>), dim3(n), dim3(256), 0, e->stream, e->slabs, nslab,
                        (long long)e->Bp * e->V, w.bv, e->V, st, w.word, w.type0, w.posd, w.embg, w.embb, e->x_f32,
-                       reinterpret_cast<T*>(e->x_t), e->cfg.ln_eps);
+                       reinterpret_cast<T*>(e->x_t), e->cfg.ln_eps, e->latent ? reinterpret_cast<T*>(e->xcache) : nullptr,
+                       (long long)e->cfg.max_len * e->D);
     HIPCHECK(hipGetLastError());
 }
 
@@ -450,6 +470,44 @@ void dec_attn(mocr_engine* e, int layer, int nslab, int n, const float* bias, in
     HIPCHECK(hipGetLastError());
 }
 
+// Latent attention of n rows: Qt [n,16,768] x keys (self: cached layer-input rows; cross: encoder
+// output) -> Et [n,16,768].  bytes: the X rows streamed once (1,536 B per key).
+void latent_attn(mocr_engine* e, bool self, int layer, int n, int approx_len) {
+    LatentParams p{};
+    p.qt = reinterpret_cast<const bf16_t*>(e->qt);
+    p.out = reinterpret_cast<bf16_t*>(e->et);
+    p.heads = e->H;
+    p.rows = n;
+    if (self) {
+        p.x = reinterpret_cast<const bf16_t*>(e->xcache) + (size_t)layer * e->Bp * e->cfg.max_len * e->D;
+        p.x_batch_stride = (long long)e->cfg.max_len * e->D;
+        p.step = e->step;
+    } else {
+        p.x = reinterpret_cast<const bf16_t*>(e->ENC);
+        p.x_batch_stride = (long long)e->S * e->D;
+        p.fixed_len = e->S;
+    }
+    ProfScope ps(e, self ? "lat_attn_self" : "lat_attn_cross", 4.0 * n * 16 * approx_len * e->D,
+                 (double)n * approx_len * e->D * 2 + 2.0 * n * 16 * e->D * 2);
+    static const int lat_blocks = env_int("MOCR_LAT_BLOCKS", 256);
+    hipLaunchKernelGGL(latent_attn_kernel, dim3(std::min(n, lat_blocks)), dim3(256), LAT_LDS, e->stream, p);
+    HIPCHECK(hipGetLastError());
+}
+
+// q -> Qt -> latent attention -> ctx: the attention block of the latent path up to (not including)
+// the output projection.  wq/bq: query projection; wkT: (Wk^T)/8; wv/bv: value projection.
+void latent_block(mocr_engine* e, bool self, int layer, int n, int t, const void* xin, const void* wq, const float* bq,
+                  const void* wkT, const void* wv, const float* bv) {
+    using T = bf16_t;
+    const int D = e->D;
+    gemm<T>(e, "gemm_dec_q", xin, D, wq, bq, e->q_t, D, nullptr, n, D, D, EPI_BIAS, 64, 1);
+    HeadBatch hq; hq.heads = e->H; hq.a_yoff = 64; hq.w_yoff = 64; hq.o_yoff = D; hq.b_yoff = 0; hq.ldw = D;
+    gemm<T>(e, "gemm_dec_qt", e->q_t, D, wkT, e->w.zero_bias, e->qt, 16 * D, nullptr, n, D, 64, EPI_BIAS, 64, 1, 0, nullptr, 0, &hq);
+    latent_attn(e, self, layer, n, self ? t + 1 : e->S);
+    HeadBatch hc; hc.heads = e->H; hc.a_yoff = D; hc.w_yoff = (long long)64 * D; hc.o_yoff = 64; hc.b_yoff = 64; hc.ldw = D;
+    gemm<T>(e, "gemm_dec_ctx", e->et, 16 * D, wv, bv, e->ctx_t, D, nullptr, n, 64, D, EPI_BIAS, 64, 1, 0, nullptr, 0, &hc);
+}
+
 // One greedy step for n rows; `t` is only used for the profiler's byte estimate.
 template <typename T>
 void decode_step(mocr_engine* e, const DecState& st, int n, int t) {
@@ -459,12 +517,24 @@ void decode_step(mocr_engine* e, const DecState& st, int n, int t) {
     const float* xres = e->x_f32;
     for (int l = 0; l < e->cfg.dec_layers; ++l) {
         const DecLayerW& L = w.dec[l];
-        int ns = dec_gemm<T>(e, "gemm_dec_qkv", xin, D, L.wqkv, 3 * D, D, n);
-        dec_attn<T, true>(e, l, ns, n, L.bqkv, t + 1);   // t = step index = keys already cached
+        int ns;
+        const size_t esz = sizeof(T);
+        if (e->latent) {
+            latent_block(e, true, l, n, t, xin, L.wqkv, L.bqkv, L.wkT_s, reinterpret_cast<const char*>(L.wqkv) + (size_t)2 * D * D * esz,
+                         L.bqkv + 2 * D);
+        } else {
+            ns = dec_gemm<T>(e, "gemm_dec_qkv", xin, D, L.wqkv, 3 * D, D, n);
+            dec_attn<T, true>(e, l, ns, n, L.bqkv, t + 1);   // t = step index = keys already cached
+        }
         ns = dec_gemm<T>(e, "gemm_dec_proj", e->ctx_t, D, L.wo, D, D, n);
         dec_add_ln<T>(e, ns, D, L.bo, xres, L.ln1g, L.ln1b, e->a_f32, e->a_t, n, false);
-        ns = dec_gemm<T>(e, "gemm_dec_proj", e->a_t, D, L.wqc, D, D, n);
-        dec_attn<T, false>(e, l, ns, n, L.bqc, e->S);
+        if (e->latent) {
+            latent_block(e, false, l, n, t, e->a_t, L.wqc, L.bqc, L.wkT_c,
+                         reinterpret_cast<const char*>(w.wckv) + (size_t)(2 * l + 1) * D * D * esz, w.bckv + (2 * l + 1) * D);
+        } else {
+            ns = dec_gemm<T>(e, "gemm_dec_proj", e->a_t, D, L.wqc, D, D, n);
+            dec_attn<T, false>(e, l, ns, n, L.bqc, e->S);
+        }
         ns = dec_gemm<T>(e, "gemm_dec_proj", e->ctx_t, D, L.woc, D, D, n);
         dec_add_ln<T>(e, ns, D, L.boc, e->a_f32, L.ln2g, L.ln2b, e->c_f32, e->c_t, n, false);
         if (pick_split(F, D, 128 / (int)sizeof(T), n, e->slab_cap / e->Bp) == 1) {
@@ -477,7 +547,8 @@ void decode_step(mocr_engine* e, const DecState& st, int n, int t) {
             HIPCHECK(hipGetLastError());
         }
         ns = dec_gemm<T>(e, "gemm_dec_fc2", e->h_t, F, L.w2, D, F, n);
-        dec_add_ln<T>(e, ns, D, L.b2, e->c_f32, L.ln3g, L.ln3b, e->x_f32, e->x_t, n, false);
+        dec_add_ln<T>(e, ns, D, L.b2, e->c_f32, L.ln3g, L.ln3b, e->x_f32, e->x_t, n, false,
+                      (e->latent && l + 1 < e->cfg.dec_layers) ? l + 1 : -1);
         xin = e->x_t; xres = e->x_f32;
     }
     int ns = dec_gemm<T>(e, "gemm_dec_proj", e->x_t, D, w.wt, D, D, n);
@@ -518,6 +589,7 @@ template <typename T> void init_kernel_attrs() {
     set_max_lds(gemm256_kernel<EPI_BIAS_RESID>, l256);
     set_max_lds(gemm256_kernel<EPI_PATCH>, l256);
     set_max_lds(gemm256_kernel<EPI_BIAS_F32>, l256);
+    set_max_lds(latent_attn_kernel, LAT_LDS);
 }
 
 // `steps` consecutive greedy steps captured once and replayed: every per-step value (position,
@@ -592,7 +664,7 @@ void start_batch(mocr_engine* e, Lane& L) {
         row0 += j.n;
     }
     run_encoder<T>(e, e->d_in, L.n);
-    run_cross_kv<T>(e, L.n);
+    if (!e->latent) run_cross_kv<T>(e, L.n);
     // rows read pad_id (= 0) beyond what the loop writes
     HIPCHECK(hipMemsetAsync(e->ids, 0, (size_t)L.n * e->cfg.max_len * sizeof(int), e->stream));
     DecState st = make_state(e, L.max_len, nullptr, 0, nullptr);
@@ -802,6 +874,16 @@ void commit_weights(mocr_engine* e) {
                                 &up.get(a + "self.value.weight", {D, D})}));
         L.bqkv = up.f32(concat({&up.get(a + "self.query.bias", {D}), &up.get(a + "self.key.bias", {D}),
                                 &up.get(a + "self.value.bias", {D})}));
+        if (e->latent) {
+            auto transposed_scaled = [&](const std::vector<float>& wk) {
+                std::vector<float> t((size_t)D * D);
+                for (int64_t o = 0; o < D; ++o)
+                    for (int64_t i = 0; i < D; ++i) t[i * D + o] = wk[o * D + i] * 0.125f;   // [in][out], 1/sqrt(64) folded in
+                return t;
+            };
+            L.wkT_s = up.mat(transposed_scaled(up.get(a + "self.key.weight", {D, D})));
+            L.wkT_c = up.mat(transposed_scaled(up.get(x + "self.key.weight", {D, D})));
+        }
         L.wo = up.mat(up.get(a + "output.dense.weight", {D, D}));
         L.bo = up.f32(up.get(a + "output.dense.bias", {D}));
         L.ln1g = up.f32(up.get(a + "output.LayerNorm.weight", {D}));
@@ -827,6 +909,7 @@ void commit_weights(mocr_engine* e) {
     }
     w.wckv = up.mat(ckv_w);
     w.bckv = up.f32(ckv_b);
+    w.zero_bias = up.f32(std::vector<float>((size_t)D, 0.f));
     const std::string cl = "decoder.cls.predictions.";
     w.wt = up.mat(up.get(cl + "transform.dense.weight", {D, D}));
     w.bt = up.f32(up.get(cl + "transform.dense.bias", {D}));
@@ -866,10 +949,17 @@ void allocate_lane(mocr_engine* e, int lane_id) {
     e->CTX = e->dalloc<char>(Mp * D * esz);
     e->Hb = e->dalloc<char>(Mp * (size_t)e->F * esz);
     e->ENC = e->dalloc<char>(Mp * D * esz);
-    e->CKV = e->dalloc<char>(Mp * (size_t)e->NCKV * esz);
-    const size_t cache = (size_t)c.dec_layers * Bp * e->H * c.max_len * 64 * esz;
-    e->kcache = e->dalloc<char>(cache);
-    e->vcache = e->dalloc<char>(cache);
+    if (e->latent) {
+        e->q_t = e->dalloc<char>(Bp * D * esz);
+        e->qt = e->dalloc<char>(Bp * 16 * D * esz);
+        e->et = e->dalloc<char>(Bp * 16 * D * esz);
+        e->xcache = e->dalloc<char>(((size_t)c.dec_layers * Bp * c.max_len + 64) * D * esz);
+    } else {
+        e->CKV = e->dalloc<char>(Mp * (size_t)e->NCKV * esz);
+        const size_t cache = (size_t)c.dec_layers * Bp * e->H * c.max_len * 64 * esz;
+        e->kcache = e->dalloc<char>(cache);
+        e->vcache = e->dalloc<char>(cache);
+    }
     e->slab_cap = (long long)Bp * 12288;
     e->slabs = e->dalloc<float>((size_t)e->slab_cap);
     e->x_f32 = e->dalloc<float>(Bp * D); e->a_f32 = e->dalloc<float>(Bp * D); e->c_f32 = e->dalloc<float>(Bp * D);
@@ -883,6 +973,7 @@ void allocate_lane(mocr_engine* e, int lane_id) {
 
 void allocate_lanes(mocr_engine* e) {
     compute_geometry(e);
+    e->latent = e->cfg.dtype == MOCR_BF16 && !(e->cfg.flags & MOCR_FLAG_CLASSIC_ATTENTION);
     const int nl = std::max(1, std::min(16, (int)e->cfg.lanes));
     e->lanes.resize(nl);
     for (int i = 0; i < nl; ++i) {
@@ -1108,7 +1199,7 @@ int mocr_decode_logits(mocr_engine* e, const void* d_gray, int32_t n, const int3
         dispatch(e, [&](auto tag) {
             using T_ = decltype(tag);
             run_encoder<T_>(e, g, n);
-            run_cross_kv<T_>(e, n);
+            if (!e->latent) run_cross_kv<T_>(e, n);
             run_decode_forced<T_>(e, n, e->forced, T, e->logits_dbg);
         });
         HIPCHECK(hipMemcpyAsync(h_logits, e->logits_dbg, lcount * 4, hipMemcpyDeviceToHost, e->stream));
@@ -1151,6 +1242,25 @@ int mocr_op_enc_attention(mocr_engine* e, const void* d_qkv, void* d_ctx, int32_
         drive(e);
         e->bind(0);
         dispatch(e, [&](auto tag) { enc_attention<decltype(tag)>(e, d_qkv, d_ctx, n, impl); });
+        HIPCHECK(hipStreamSynchronize(e->stream));
+    });
+}
+
+int mocr_op_latent_attention(mocr_engine* e, const void* d_qt, const void* d_x, void* d_out, int32_t n, int32_t len,
+                             int64_t x_batch_stride) {
+    return guarded(e, [&] {
+        std::lock_guard<std::mutex> lk(e->mu);
+        HIPCHECK(hipSetDevice(e->cfg.device));
+        drive(e);
+        e->bind(0);
+        if (e->cfg.dtype != MOCR_BF16 || !d_qt || !d_x || !d_out || n < 1 || len < 1) throw ArgError{"bad argument", MOCR_ERR_ARG};
+        LatentParams p{};
+        p.qt = reinterpret_cast<const bf16_t*>(d_qt); p.x = reinterpret_cast<const bf16_t*>(d_x);
+        p.out = reinterpret_cast<bf16_t*>(d_out); p.x_batch_stride = x_batch_stride; p.fixed_len = len; p.heads = e->H;
+        p.ablate = env_int("MOCR_LAT_ABLATE", 0); p.rows = n;
+        ProfScope ps(e, "op_latent", 0, (double)n * len * 1536);
+        hipLaunchKernelGGL(latent_attn_kernel, dim3(std::min((int)n, env_int("MOCR_LAT_BLOCKS", 256))), dim3(256), LAT_LDS, e->stream, p);
+        HIPCHECK(hipGetLastError());
         HIPCHECK(hipStreamSynchronize(e->stream));
     });
 }

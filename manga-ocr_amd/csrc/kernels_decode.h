@@ -14,7 +14,9 @@ template <typename T, int D, bool GELU>
 __global__ __launch_bounds__(D / 4) void dec_add_ln_kernel(const float* __restrict__ slabs, int nslab, long long slab_stride,
                                                            const float* __restrict__ bias, const float* __restrict__ resid,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           float* __restrict__ out_f32, T* __restrict__ out_t, int rows, float eps) {
+                                                           float* __restrict__ out_f32, T* __restrict__ out_t, int rows, float eps,
+                                                           T* __restrict__ cache = nullptr, long long cache_batch_stride = 0,
+                                                           const int* __restrict__ step = nullptr) {
     constexpr int NW = D / 256;                      // waves per block
     __shared__ float s_red[2][NW];
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -64,6 +66,8 @@ __global__ __launch_bounds__(D / 4) void dec_add_ln_kernel(const float* __restri
                   (v[3] - mean) * rstd * g.w + b.w};
     if (out_f32) *reinterpret_cast<float4*>(out_f32 + (size_t)row * D + c) = make_float4(o[0], o[1], o[2], o[3]);
     elem<T>::st4(out_t + (size_t)row * D + c, o);
+    // latent attention: this row is also the key/value source of position step[row] for the next layer
+    if (cache) elem<T>::st4(cache + (size_t)row * cache_batch_stride + (size_t)step[row] * D + c, o);
 }
 
 // out T = gelu( sum_s slab_s + bias )   (the decoder FFN's intermediate activation)
@@ -118,7 +122,8 @@ __global__ __launch_bounds__(256) void dec_token_kernel(const float* __restrict_
                                                         const float* __restrict__ word, const float* __restrict__ type0,
                                                         const float* __restrict__ pos, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float* __restrict__ x_f32,
-                                                        T* __restrict__ x_t, float eps) {
+                                                        T* __restrict__ x_t, float eps, T* __restrict__ cache = nullptr,
+                                                        long long cache_batch_stride = 0) {
     __shared__ float s_val[4];
     __shared__ int s_idx[4];
     __shared__ float s_red[4];
@@ -212,5 +217,6 @@ __global__ __launch_bounds__(256) void dec_token_kernel(const float* __restrict_
         const float o = (v[i] - mean) * rstd * gamma[d] + beta[d];
         x_f32[(size_t)b * D + d] = o;
         elem<T>::st(x_t + (size_t)b * D + d, o);
+        if (cache) elem<T>::st(cache + (size_t)b * cache_batch_stride + (size_t)ps * D + d, o);   // layer-0 key/value source
     }
 }

@@ -44,6 +44,7 @@ struct GemmParams {
     long long slab_stride; // EPI_SLAB: elements between slabs
     int ntn;               // tiles along N
     int patches;           // EPI_PATCH: patches per image (196)
+    long long a_yoff, w_yoff, o_yoff, b_yoff;  // element offsets per blockIdx.y (per-head batched GEMMs; EPI_BIAS only)
     int ablate;            // diagnostics only (MOCR_GEMM_ABLATE): 1 no MFMA, 2 no DMA after tile 0, 4 no epilogue
 };
 
@@ -129,8 +130,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     const int kbeg = blockIdx.z * p.k_per_split;
     const int nt = p.k_per_split / (128 / (int)sizeof(T));
 
-    const char* Ab = (const char*)p.A + ((size_t)m0 * p.lda + kbeg) * sizeof(T);
-    const char* Wb = (const char*)p.W + ((size_t)n0 * p.ldw + kbeg) * sizeof(T);
+    const char* Ab = (const char*)p.A + ((size_t)m0 * p.lda + kbeg + (size_t)blockIdx.y * p.a_yoff) * sizeof(T);
+    const char* Wb = (const char*)p.W + ((size_t)n0 * p.ldw + kbeg + (size_t)blockIdx.y * p.w_yoff) * sizeof(T);
     const size_t a_row = (size_t)p.lda * sizeof(T), w_row = (size_t)p.ldw * sizeof(T);
 
     // per-lane part of the staging addresses: lane -> (row within 8-row piece, physical chunk)
@@ -238,7 +239,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
             }
     __syncthreads();
 
-    gemm_epilogue<T, BM, BN, EPI, 256>(sC, p, m0, n0, tid, blockIdx.z);
+    if constexpr (EPI == EPI_BIAS) {
+        GemmParams q = p;
+        q.out = reinterpret_cast<T*>(p.out) + (size_t)blockIdx.y * p.o_yoff;
+        q.bias = p.bias + (size_t)blockIdx.y * p.b_yoff;
+        gemm_epilogue<T, BM, BN, EPI, 256>(sC, q, m0, n0, tid, blockIdx.z);
+    } else {
+        gemm_epilogue<T, BM, BN, EPI, 256>(sC, p, m0, n0, tid, blockIdx.z);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

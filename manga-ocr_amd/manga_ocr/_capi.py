@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "_lib", "libmocr_hip.so")
 
 MOCR_OK = 0
 MOCR_F32, MOCR_BF16 = 0, 1
-FLAG_SIMPLE_ATTENTION, FLAG_NO_GRAPH, FLAG_NO_EARLY_EXIT = 1, 2, 4
+FLAG_SIMPLE_ATTENTION, FLAG_NO_GRAPH, FLAG_NO_EARLY_EXIT, FLAG_CLASSIC_ATTENTION = 1, 2, 4, 8
 EPI_SLAB, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_PATCH, EPI_BIAS_F32 = range(6)
 
 
@@ -46,6 +46,7 @@ SYMBOLS = {
     "mocr_op_gemm": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "mocr_op_layernorm": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32]),
     "mocr_op_enc_attention": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32]),
+    "mocr_op_latent_attention": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int64]),
     "mocr_profile_enable": (C.c_int, [_P, C.c_int32]),
     "mocr_profile_reset": (C.c_int, [_P]),
     "mocr_profile_get": (C.c_int, [_P, C.POINTER(MocrKernelStat), C.c_int32, C.POINTER(C.c_int32)]),

@@ -131,6 +131,9 @@ class Engine:
     def op_enc_attention(self, d_qkv, d_ctx, n, impl) -> None:
         self._check(self.lib.mocr_op_enc_attention(self._h, _ptr(d_qkv), _ptr(d_ctx), n, impl))
 
+    def op_latent_attention(self, d_qt, d_x, d_out, n, length, x_batch_stride) -> None:
+        self._check(self.lib.mocr_op_latent_attention(self._h, _ptr(d_qt), _ptr(d_x), _ptr(d_out), n, length, x_batch_stride))
+
     # ------------------------------------------------------------------ per-kernel timing
     def profile_enable(self, on: bool = True) -> None:
         self._check(self.lib.mocr_profile_enable(self._h, 1 if on else 0))

@@ -155,3 +155,31 @@ def test_encoder_attention(dtype, impl):
     report(f"enc attention {dtype} impl{impl}: max abs err {err:.3e} (|ref| max {np.abs(ref).max():.2f})")
     assert np.isfinite(got).all()
     assert err <= tol
+
+
+@pytest.mark.parametrize("L,n", [(1, 5), (5, 5), (32, 5), (33, 5), (64, 5), (197, 5), (300, 5),
+                                 (20, 300), (40, 300), (70, 700), (197, 520)])
+def test_latent_attention(L, n):
+    """softmax(Qt X^T) X per head with the heads on the MFMA rows; keys streamed through the LDS ring
+    in tiles of 32 (L = 1 .. 300 covers 1 to 10 tiles, partial last tiles and the ring's drain)."""
+    eng = engine("bf16")
+    rs = np.random.RandomState(L)
+    H, D = 12, 768      # n > 256: persistent blocks take several sequences each (1, 2 and 3+ tile rows)
+    stride = (L + 7) * D                                      # sequences are not tile-aligned in memory
+    qt = np.zeros((n, 16, D), np.float32)
+    qt[:, :H] = bf16_round((rs.standard_normal((n, H, D)) * 0.08).astype(np.float32))
+    x = bf16_round(rs.standard_normal((n * (L + 7) + 64, D)).astype(np.float32))     # + rows a last tile may touch
+    xs = np.stack([x[b * (L + 7): b * (L + 7) + L] for b in range(n)]).astype(np.float64)   # [n,L,D]
+    sc = np.einsum("bhd,bkd->bhk", qt[:, :H].astype(np.float64), xs)
+    sc -= sc.max(-1, keepdims=True)
+    pr = np.exp(sc)
+    pr /= pr.sum(-1, keepdims=True)
+    ref = np.einsum("bhk,bkd->bhd", pr, xs)
+    dq, dx = _dev(qt, "bf16"), _dev(x, "bf16")
+    do = torch.full((n, 16, D), float("nan"), device="cuda", dtype=torch.bfloat16)
+    torch.cuda.synchronize()
+    eng.op_latent_attention(dq, dx, do, n, L, stride)
+    got = do[:, :H].float().cpu().numpy().astype(np.float64)
+    err = np.abs(got - ref).max()
+    report(f"latent attention L={L}: max abs err {err:.3e} (|ref| max {np.abs(ref).max():.2f})")
+    assert np.isfinite(got).all() and err <= 3e-2
