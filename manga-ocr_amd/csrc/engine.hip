@@ -1258,10 +1258,23 @@ int mocr_op_latent_attention(mocr_engine* e, const void* d_qt, const void* d_x, 
         p.qt = reinterpret_cast<const bf16_t*>(d_qt); p.x = reinterpret_cast<const bf16_t*>(d_x);
         p.out = reinterpret_cast<bf16_t*>(d_out); p.x_batch_stride = x_batch_stride; p.fixed_len = len; p.heads = e->H;
         p.ablate = env_int("MOCR_LAT_ABLATE", 0); p.rows = n;
+        static unsigned long long* dbg = nullptr;
+        if (env_int("MOCR_LAT_STAMP", 0)) { if (!dbg) dbg = e->dalloc<unsigned long long>(8 + 512); p.dbg = dbg; }
         ProfScope ps(e, "op_latent", 0, (double)n * len * 1536);
         hipLaunchKernelGGL(latent_attn_kernel, dim3(std::min((int)n, env_int("MOCR_LAT_BLOCKS", 256))), dim3(256), LAT_LDS, e->stream, p);
         HIPCHECK(hipGetLastError());
         HIPCHECK(hipStreamSynchronize(e->stream));
+        if (p.dbg) {
+            unsigned long long h[8];
+            HIPCHECK(hipMemcpy(h, p.dbg, sizeof(h), hipMemcpyDeviceToHost));
+            if (env_int("MOCR_LAT_DUMP", 0)) {
+                std::vector<float> f(1024);
+                HIPCHECK(hipMemcpy(f.data(), p.dbg + 8, 1024 * 4, hipMemcpyDeviceToHost));
+                FILE* fp = fopen("gpurun_out/lat_dump.bin", "wb");
+                if (fp) { fwrite(f.data(), 4, 1024, fp); fclose(fp); }
+            }
+            fprintf(stderr, "[lat stamps, cycles] wait+issue %llu  S %llu  exchange %llu  softmax %llu  PX %llu  other %llu\n", h[0], h[1], h[2], h[3], h[4], h[5]);
+        }
     });
 }
 

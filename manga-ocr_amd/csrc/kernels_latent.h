@@ -39,6 +39,7 @@ struct LatentParams {
     int fixed_len;
     int heads;                  // 12
     int rows;                   // sequences
+    unsigned long long* dbg;    // diagnostics: per-segment cycle sums of block 0 / wave 0 (s_memtime), 8 slots; null normally
     int ablate;                 // diagnostics (MOCR_LAT_ABLATE): 1 no S MFMAs, 2 no softmax reductions, 4 no P.X, 8 no DMA after tile 1
 };
 
@@ -50,8 +51,15 @@ __device__ __forceinline__ int lat_off(int r, int c) { return r * (LAT_D * 2) + 
 template <int N> __device__ __forceinline__ float dpp_ror(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xf, 0xf, false));
 }
+// max(v, v rotated by N inside its 16-lane row) as ONE instruction; the s_nop covers the
+// "VALU write -> DPP read" hazard (2 wait states), which hipcc does not pad inside asm (§5.7 item 2)
+#define DPP_MAX_STEP(v, N) asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 row_ror:" #N " row_mask:0xf bank_mask:0xf" : "=v"(v) : "v"(v))
 __device__ __forceinline__ float row16_max(float v) {
+#ifdef MOCR_ASM_DPP_MAX
+    DPP_MAX_STEP(v, 8); DPP_MAX_STEP(v, 4); DPP_MAX_STEP(v, 2); DPP_MAX_STEP(v, 1);
+#else
     v = fmaxf(v, dpp_ror<8>(v)); v = fmaxf(v, dpp_ror<4>(v)); v = fmaxf(v, dpp_ror<2>(v)); v = fmaxf(v, dpp_ror<1>(v));
+#endif
     return v;
 }
 __device__ __forceinline__ float row16_sum(float v) {
@@ -75,6 +83,10 @@ __device__ __forceinline__ void tr_read6(uint2* o, const unsigned* a) {
         : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5])
         : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5])
         : "memory");
+}
+__device__ __forceinline__ void lds_read2_b128(uint4* o, unsigned a0, unsigned a1) {
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(o[0]), "=&v"(o[1]) : "v"(a0), "v"(a1) : "memory");
 }
 __device__ __forceinline__ void lds_read3_b128(uint4* o, unsigned a0, unsigned a1, unsigned a2) {
     asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %4\n\tds_read_b128 %2, %5\n\ts_waitcnt lgkmcnt(0)"
@@ -114,7 +126,7 @@ __device__ __forceinline__ void wait_vm_newer(int newer) {
 }
 
 // request one 48 KiB tile: 12 DMA instructions per wave (src_off: this lane's 12 source offsets)
-__device__ __forceinline__ void lat_stage(const char* src, char* dst, const int (&src_off)[12], int wave) {
+__device__ __forceinline__ void lat_stage(const char* src, char* dst, const unsigned (&src_off)[12], int wave) {
 #pragma unroll
     for (int i = 0; i < 12; ++i) glds16(src + src_off[i], dst + (wave + 4 * i) * 1024);
 }
@@ -127,10 +139,29 @@ __global__ __launch_bounds__(256, 1) void latent_attn_kernel(LatentParams p) {
     const bf16_t* const P_x = p.x;
     bf16_t* const P_out = p.out;
     const long long P_xstride = p.x_batch_stride;
-    const int P_rows = p.rows, P_heads = p.heads, P_ablate = p.ablate;
+    const int P_rows = p.rows, P_heads = p.heads;
+    // Diagnostic cycle stamps (s_memtime) are compiled in only with -DMOCR_LAT_STAMPS: a runtime
+    // "if (dbg)" branch right behind an MFMA chain jumps over the compiler's hazard padding
+    // (MFMA write -> v_accvgpr_read) and silently corrupts the last accumulator.
+#ifdef MOCR_LAT_STAMPS
+    unsigned long long* const P_dbg = p.dbg;
+    unsigned long long tsum[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+#define STAMP(k)                                                                                   \
+    {                                                                                              \
+        unsigned long long tn;                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tn)::"memory");                    \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        tsum[k] += tn - tprev;                                                                     \
+        tprev = tn;                                                                                \
+    }
+#else
+#define STAMP(k)
+#endif
     (void)P_heads;
     float* sS = reinterpret_cast<float*>(smem + LAT_NST * LAT_TILE_BYTES);        // [4][16][32] partial scores
-    bf16_t* sP = reinterpret_cast<bf16_t*>(sS + 4 * 16 * 32);                      // [4][16][32] probabilities
+    bf16_t* sP = reinterpret_cast<bf16_t*>(sS + 4 * 16 * 32);                      // [16][32] probabilities (1 KiB of a 4 KiB area)
+    float* sAl = reinterpret_cast<float*>(sP + 16 * 32);                           // [16] per-head rescale factors, then [16] row sums
     bf16_t* sO = reinterpret_cast<bf16_t*>(sS);                                    // [8 heads][768] output staging (12 KiB)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
@@ -142,13 +173,13 @@ __global__ __launch_bounds__(256, 1) void latent_attn_kernel(LatentParams p) {
 
     // DMA source offsets of this lane for the 12 pieces a wave copies per tile: piece pc covers the
     // linear 16-byte chunks 64*pc .. 64*pc+63 of the tile image
-    int src_off[12];
+    unsigned src_off[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
         const int gch = 64 * (wave + 4 * i) + lane;      // 0 .. 3071
         const int r = gch / 96, cp = gch - r * 96;       // key row, physical chunk
         const int c = (cp & ~15) | ((cp ^ r) & 15);      // logical chunk stored there
-        src_off[i] = r * (LAT_D * 2) + c * 16;
+        src_off[i] = (unsigned)(r * (LAT_D * 2) + c * 16);
     }
     // byte offsets (inside a tile image) of this lane's transposed block reads for keys 8g .. 8g+3, one
     // per column tile; the block of keys 8g+4 .. 8g+7 is 4 rows further with chunk bit 2 flipped by the
@@ -162,6 +193,12 @@ __global__ __launch_bounds__(256, 1) void latent_attn_kernel(LatentParams p) {
             tr_off[dt] = lat_off(r0, c) + 8 * (p4 & 1);
         }
     }
+    // byte offsets (inside a tile image) of this lane's 12 row reads of the S product: [sub-tile j][k-step s]
+    unsigned s_off[12];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int s = 0; s < 6; ++s) s_off[6 * j + s] = lat_off(16 * j + l15, 24 * wave + 4 * s + g);
     const unsigned smem_base = lds_addr(smem);
     // A operand of the S product: Qt[head = lane&15][192*wave + 32*s + 8*g .. +7]
     const bf16_t* const q_lane = P_qt + (size_t)l15 * LAT_D + 192 * wave + 8 * g;
@@ -208,18 +245,18 @@ __global__ __launch_bounds__(256, 1) void latent_attn_kernel(LatentParams p) {
         for (int dt = 0; dt < 12; ++dt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) cacc[dt][r] = 0.f;
-        float m_run[4], l_run[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { m_run[r] = -INFINITY; l_run[r] = 0.f; }
+        float m_run = -INFINITY, l_run = 0.f;       // this wave's heads {4g + wave}
 
         for (int t = 0; t < cnt; ++t) {
+            STAMP(5)   // everything since the last stamp of the previous tile (loop overhead, row end)
             // the tile of `slot` has landed: allow exactly the instructions issued after its request
             wait_vm_newer(issued - (slot == 0 ? mk0 : slot == 1 ? mk1 : mk2));
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (!(P_ablate & 8)) ISSUE_NEXT();    // refills the slot every wave has finished reading
+            ISSUE_NEXT();                         // refills the slot every wave has finished reading
             const char* xt = smem + slot * LAT_TILE_BYTES;
             slot = slot + 1 == LAT_NST ? 0 : slot + 1;
+            STAMP(0)   // wait + barrier + DMA issue
 
             // ---- partial scores over this wave's 192 dims: S[head][key], two 16-key sub-tiles
             f32x4 sacc[2];
@@ -227,15 +264,13 @@ __global__ __launch_bounds__(256, 1) void latent_attn_kernel(LatentParams p) {
             for (int j = 0; j < 2; ++j) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) sacc[j][r] = 0.f;
-                const int key = 16 * j + l15;
-                if (!(P_ablate & 1))
 #pragma unroll
                     for (int s = 0; s < 6; ++s) {
-                        const int c = 24 * wave + 4 * s + g;
-                        const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xt + lat_off(key, c));
+                        const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xt + s_off[6 * j + s]);
                         sacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[s], xf, sacc[j], 0, 0, 0);
                     }
             }
+            STAMP(1)   // S-phase reads + MFMAs
             // C/D map of the 16x16 MFMA: col = lane&15 (key), row = 4*(lane>>4) + reg (head)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
@@ -244,46 +279,55 @@ __global__ __launch_bounds__(256, 1) void latent_attn_kernel(LatentParams p) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            float sv[2][4];
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int o = (4 * g + r) * 32 + 16 * j + l15;
-                    sv[j][r] = (sS[o] + sS[512 + o]) + (sS[1024 + o] + sS[1536 + o]);
-                }
-            // ---- online softmax per head (4 heads per lane; a head's 32 keys sit on 16 lanes x 2)
-            const bool ok0 = t * LAT_TK + l15 < L, ok1 = t * LAT_TK + 16 + l15 < L;
-            float alpha[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float v0 = ok0 ? sv[0][r] : -INFINITY, v1 = ok1 ? sv[1][r] : -INFINITY;
-                float mx = fmaxf(v0, v1);
-                if (!(P_ablate & 2)) mx = row16_max(mx);
-                const float mn = fmaxf(m_run[r], mx);            // finite: every tile has a valid key
-                alpha[r] = __expf(m_run[r] - mn);
+            // ---- online softmax, split over the waves: wave w owns accumulator register r = w, i.e. heads
+            // {4g + w}; a head's 32 keys sit on the 16 lanes of its group x 2 sub-tiles
+            float v0, v1;
+            {
+                const int o = (4 * g + wave) * 32 + l15;
+                v0 = (sS[o] + sS[512 + o]) + (sS[1024 + o] + sS[1536 + o]);
+                v1 = (sS[o + 16] + sS[512 + o + 16]) + (sS[1024 + o + 16] + sS[1536 + o + 16]);
+            }
+            STAMP(2)   // partial-score exchange through LDS (write, barrier, read)
+            if (t * LAT_TK + l15 >= L) v0 = -INFINITY;
+            if (t * LAT_TK + 16 + l15 >= L) v1 = -INFINITY;
+            {
+                float mx = v0 > v1 ? v0 : v1;
+                mx = row16_max(mx);
+                const float mn = mx > m_run ? mx : m_run;          // finite: every tile has a valid key
+                const float al = __expf(m_run - mn);
                 const float p0 = __expf(v0 - mn), p1 = __expf(v1 - mn);
-                float ps = p0 + p1;
-                if (!(P_ablate & 2)) ps = row16_sum(ps);
-                l_run[r] = l_run[r] * alpha[r] + ps;
-                m_run[r] = mn;
-                bf16_t* pw = sP + (wave * 16 + 4 * g + r) * 32 + l15;
+                l_run = l_run * al + row16_sum(p0 + p1);
+                m_run = mn;
+                bf16_t* pw = sP + (4 * g + wave) * 32 + l15;        // shared P[head][key]
                 pw[0] = f2bf(p0);
                 pw[16] = f2bf(p1);
+                if (l15 == 0) sAl[4 * g + wave] = al;               // shared alpha[head]
             }
-            // rescale the accumulators only when some head's running max moved (wave-uniform test)
-            if (__any((alpha[0] != 1.0f) | (alpha[1] != 1.0f) | (alpha[2] != 1.0f) | (alpha[3] != 1.0f))) {
-#pragma unroll
-                for (int dt = 0; dt < 12; ++dt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) cacc[dt][r] *= alpha[r];
-            }
-            // sP is private to the wave: LDS is in order per wave, only the counter must be waited for
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            // alpha[4g..4g+3] and the A operand P[head = lane&15][key = 8*g + jj] through inline asm: a plain
+            // LDS load here gets a compiler s_waitcnt vmcnt(0) in front (DMA-alias conservatism)
+            uint4 ap[2];
+            lds_read2_b128(ap, lds_addr(sAl) + 16 * g, lds_addr(sP) + (l15 * 32 + 8 * g) * 2);
+            __builtin_amdgcn_sched_barrier(0);
+            // rescale the accumulators only when some head's running max moved (wave-uniform test)
+            {
+                const float a0 = __uint_as_float(ap[0].x), a1 = __uint_as_float(ap[0].y), a2 = __uint_as_float(ap[0].z),
+                            a3 = __uint_as_float(ap[0].w);
+                if (__any((a0 != 1.0f) | (a1 != 1.0f) | (a2 != 1.0f) | (a3 != 1.0f))) {
+#pragma unroll
+                    for (int dt = 0; dt < 12; ++dt) {
+                        cacc[dt][0] *= a0; cacc[dt][1] *= a1; cacc[dt][2] *= a2; cacc[dt][3] *= a3;
+                    }
+                }
+            }
+            STAMP(3)   // softmax + rescale
             // ---- C[head][d] += P[head][key] X[key][d] over this wave's 192 columns
-            // A operand: P[head = lane&15][key = 8*g + jj]
-            const bf16x8 pf = *reinterpret_cast<const bf16x8*>(sP + (wave * 16 + l15) * 32 + 8 * g);
-            if (!(P_ablate & 4)) {
+            union { uint4 u; bf16x8 v; } pcv;
+            pcv.u = ap[1];
+            const bf16x8 pf = pcv.v;
+            {
                 // B operand: X[key = 8*g + jj][d0 + (lane&15)], read transposed: lane 4q+p of a 16-lane group
                 // supplies the address of row q, columns 4p..4p+3 of a 4 x 16 block and receives column
                 // (lane&15) of the 4 rows.  Two read groups of six column tiles each.
@@ -308,12 +352,22 @@ __global__ __launch_bounds__(256, 1) void latent_attn_kernel(LatentParams p) {
                     }
                 }
             }
+            STAMP(4)   // P read + transposed reads + P.X MFMAs
         }
         // ---- finish the row: normalise, stage through LDS (two halves of 8 heads x 768 bf16 = 12 KiB,
         // the score/probability scratch), store with 3 + 3 full 16-byte accesses per thread
+        if (l15 == 0) sAl[16 + 4 * g + wave] = l_run;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
         float inv[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) inv[r] = 1.0f / l_run[r];
+        {
+            uint4 l4;     // inline asm for the same reason as the alpha/P read above
+            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(l4) : "v"(lds_addr(sAl) + 64 + 16 * g) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            inv[0] = 1.0f / __uint_as_float(l4.x); inv[1] = 1.0f / __uint_as_float(l4.y);
+            inv[2] = 1.0f / __uint_as_float(l4.z); inv[3] = 1.0f / __uint_as_float(l4.w);
+        }
         char* ob = reinterpret_cast<char*>(P_out + (size_t)cr * 16 * LAT_D);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
@@ -353,6 +407,11 @@ __global__ __launch_bounds__(256, 1) void latent_attn_kernel(LatentParams p) {
         cr += nblk;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef MOCR_LAT_STAMPS
+    if (P_dbg && blockIdx.x == 0 && tid == 0)
+        for (int k = 0; k < 6; ++k) P_dbg[k] = tsum[k];
+#endif
+#undef STAMP
 #undef ISSUE_NEXT
 #undef Q_PTR
 }
