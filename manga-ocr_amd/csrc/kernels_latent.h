@@ -84,6 +84,32 @@ __device__ __forceinline__ void tr_read6(uint2* o, const unsigned* a) {
         : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5])
         : "memory");
 }
+// twelve row reads (the whole S operand of a tile: 2 sub-tiles x 6 k-steps) in flight at once
+__device__ __forceinline__ void lds_read12_b128(uint4* o, const unsigned* a) {
+    asm volatile(
+        "ds_read_b128 %0, %12\n\tds_read_b128 %1, %13\n\tds_read_b128 %2, %14\n\tds_read_b128 %3, %15\n\t"
+        "ds_read_b128 %4, %16\n\tds_read_b128 %5, %17\n\tds_read_b128 %6, %18\n\tds_read_b128 %7, %19\n\t"
+        "ds_read_b128 %8, %20\n\tds_read_b128 %9, %21\n\tds_read_b128 %10, %22\n\tds_read_b128 %11, %23\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]),
+          "=&v"(o[8]), "=&v"(o[9]), "=&v"(o[10]), "=&v"(o[11])
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8]), "v"(a[9]),
+          "v"(a[10]), "v"(a[11])
+        : "memory");
+}
+__device__ __forceinline__ void tr_read12(uint2* o, const unsigned* a) {
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %12\n\tds_read_b64_tr_b16 %1, %13\n\tds_read_b64_tr_b16 %2, %14\n\t"
+        "ds_read_b64_tr_b16 %3, %15\n\tds_read_b64_tr_b16 %4, %16\n\tds_read_b64_tr_b16 %5, %17\n\t"
+        "ds_read_b64_tr_b16 %6, %18\n\tds_read_b64_tr_b16 %7, %19\n\tds_read_b64_tr_b16 %8, %20\n\t"
+        "ds_read_b64_tr_b16 %9, %21\n\tds_read_b64_tr_b16 %10, %22\n\tds_read_b64_tr_b16 %11, %23\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]),
+          "=&v"(o[8]), "=&v"(o[9]), "=&v"(o[10]), "=&v"(o[11])
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8]), "v"(a[9]),
+          "v"(a[10]), "v"(a[11])
+        : "memory");
+}
 __device__ __forceinline__ void lds_read2_b128(uint4* o, unsigned a0, unsigned a1) {
     asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
                  : "=&v"(o[0]), "=&v"(o[1]) : "v"(a0), "v"(a1) : "memory");
@@ -258,17 +284,29 @@ __global__ __launch_bounds__(256, 1) void latent_attn_kernel(LatentParams p) {
             slot = slot + 1 == LAT_NST ? 0 : slot + 1;
             STAMP(0)   // wait + barrier + DMA issue
 
-            // ---- partial scores over this wave's 192 dims: S[head][key], two 16-key sub-tiles
+            // ---- partial scores over this wave's 192 dims: S[head][key], two 16-key sub-tiles.  All twelve
+            // operand reads are issued before the first MFMA (left to itself hipcc serialises
+            // read -> wait -> MFMA twelve times through one register quad)
+            const unsigned xt_a = smem_base + (unsigned)(xt - smem);
             f32x4 sacc[2];
+            {
+                unsigned sa[12];
+                uint4 xs[12];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+                for (int k = 0; k < 12; ++k) sa[k] = xt_a + s_off[k];
+                lds_read12_b128(xs, sa);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) sacc[j][r] = 0.f;
+                for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sacc[j][r] = 0.f;
 #pragma unroll
                     for (int s = 0; s < 6; ++s) {
-                        const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xt + s_off[6 * j + s]);
-                        sacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[s], xf, sacc[j], 0, 0, 0);
+                        union { uint4 u; bf16x8 v; } cv;
+                        cv.u = xs[6 * j + s];
+                        sacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[s], cv.v, sacc[j], 0, 0, 0);
                     }
+                }
             }
             STAMP(1)   // S-phase reads + MFMAs
             // C/D map of the 16x16 MFMA: col = lane&15 (key), row = 4*(lane>>4) + reg (head)
@@ -330,25 +368,24 @@ __global__ __launch_bounds__(256, 1) void latent_attn_kernel(LatentParams p) {
             {
                 // B operand: X[key = 8*g + jj][d0 + (lane&15)], read transposed: lane 4q+p of a 16-lane group
                 // supplies the address of row q, columns 4p..4p+3 of a 4 x 16 block and receives column
-                // (lane&15) of the 4 rows.  Two read groups of six column tiles each.
-                const unsigned xt_a = smem_base + (unsigned)(xt - smem);
+                // (lane&15) of the 4 rows.  Two read groups of six column tiles (12 block reads) each.
 #pragma unroll
-                for (int grp = 0; grp < 4; ++grp) {
-                    unsigned ad[6];
-                    uint2 xr[6];
+                for (int grp = 0; grp < 2; ++grp) {
+                    unsigned ad[12];
+                    uint2 xr[12];
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        const unsigned lo = tr_off[3 * grp + k];
+                    for (int k = 0; k < 6; ++k) {
+                        const unsigned lo = tr_off[6 * grp + k];
                         ad[2 * k] = xt_a + lo;
                         ad[2 * k + 1] = xt_a + ((lo + 4 * LAT_D * 2) ^ 64u);
                     }
-                    tr_read6(xr, ad);
+                    tr_read12(xr, ad);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) {
+                    for (int k = 0; k < 6; ++k) {
                         union { uint4 u; bf16x8 v; } cv;
                         cv.u = make_uint4(xr[2 * k].x, xr[2 * k].y, xr[2 * k + 1].x, xr[2 * k + 1].y);
-                        cacc[3 * grp + k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, cv.v, cacc[3 * grp + k], 0, 0, 0);
+                        cacc[6 * grp + k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, cv.v, cacc[6 * grp + k], 0, 0, 0);
                     }
                 }
             }

@@ -16,21 +16,15 @@ from manga_ocr.weights import DEFAULT_SPEC, synthetic_weights  # noqa: E402
 EPI = {"slab": 0, "bias": 1, "gelu": 2, "resid": 3, "f32": 5}
 
 SHAPES = [  # (name, M, N, K, epi, tile, split)
-    ("enc_qkv", 100864, 2304, 768, "bias", 128, 1), ("enc_oproj", 100864, 768, 768, "resid", 128, 1),
-    ("enc_fc1", 100864, 3072, 768, "gelu", 128, 1), ("enc_fc1_nogelu", 100864, 3072, 768, "bias", 128, 1),
-    ("enc_fc2", 100864, 768, 3072, "resid", 128, 1),
-    ("enc_qkv 256", 100864, 2304, 768, "bias", 256, 1), ("enc_oproj 256", 100864, 768, 768, "resid", 256, 1),
-    ("enc_fc1 256", 100864, 3072, 768, "gelu", 256, 1), ("enc_fc2 256", 100864, 768, 3072, "resid", 256, 1),
-    ("enc_ckv 256", 100864, 3072, 768, "bias", 256, 1), ("enc_fc2 256 b256", 50432, 768, 3072, "resid", 256, 1),
-    ("dec_proj t64 s2", 512, 768, 768, "slab", 64, 2), ("dec_proj t64 s12", 512, 768, 768, "slab", 64, 12),
-    ("dec_proj t128 s4", 512, 768, 768, "slab", 128, 4), ("dec_proj t128 s12", 512, 768, 768, "slab", 128, 12),
-    ("dec_proj t64 s1 bias", 512, 768, 768, "bias", 64, 1),
-    ("dec_fc1 t64 gelu", 512, 3072, 768, "gelu", 64, 1), ("dec_fc1 t128 gelu", 512, 3072, 768, "gelu", 128, 1),
-    ("dec_fc2 t64 s4", 512, 768, 3072, "slab", 64, 4), ("dec_fc2 t64 s16", 512, 768, 3072, "slab", 64, 16),
-    ("dec_fc2 t128 s8", 512, 768, 3072, "slab", 128, 8),
-    ("dec_vocab t64 s1", 512, 6144, 768, "slab", 64, 1), ("dec_vocab t128 s1", 512, 6144, 768, "slab", 128, 1),
-    ("dec_vocab t128 s2", 512, 6144, 768, "slab", 128, 2),
-    ("dec_proj64 t64 s12", 64, 768, 768, "slab", 64, 12), ("dec_vocab64 t64 s2", 64, 6144, 768, "slab", 64, 2),
+    ("dec_q t64", 2048, 768, 768, "bias", 64, 1), ("dec_q t128", 2048, 768, 768, "bias", 128, 1),
+    ("dec_proj t64 s1", 2048, 768, 768, "slab", 64, 1), ("dec_proj t64 s2", 2048, 768, 768, "slab", 64, 2),
+    ("dec_proj t128 s1", 2048, 768, 768, "slab", 128, 1), ("dec_proj t128 s2", 2048, 768, 768, "slab", 128, 2),
+    ("dec_proj t128 s4", 2048, 768, 768, "slab", 128, 4),
+    ("dec_fc1 t64 gelu", 2048, 3072, 768, "gelu", 64, 1), ("dec_fc1 t128 gelu", 2048, 3072, 768, "gelu", 128, 1),
+    ("dec_fc2 t64 s1", 2048, 768, 3072, "slab", 64, 1), ("dec_fc2 t128 s1", 2048, 768, 3072, "slab", 128, 1),
+    ("dec_fc2 t128 s2", 2048, 768, 3072, "slab", 128, 2), ("dec_fc2 t128 s4", 2048, 768, 3072, "slab", 128, 4),
+    ("dec_vocab t64 s1", 2048, 6144, 768, "slab", 64, 1), ("dec_vocab t128 s1", 2048, 6144, 768, "slab", 128, 1),
+    ("dec_vocab t256", 2048, 6144, 768, "f32", 256, 1),
 ]
 
 
