@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--fetch")
     ap.add_argument("--write")
     ap.add_argument("--note", default="")
+    ap.add_argument("--rows", type=int, default=0, help="rows of the merged batch the PMC passes ran")
     a = ap.parse_args()
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
@@ -43,7 +44,7 @@ def main():
         shutil.copy(os.path.join(a.stats, f), os.path.join(out, f"{a.round}_kernel_stats.csv"))
     if a.fetch and a.write:
         fe, wr = pmc(a.fetch), pmc(a.write)
-        res = {"note": a.note, "correction": "traffic_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE reads half of a 16 B/lane stream)",
+        res = {"note": a.note, "rows": a.rows, "correction": "traffic_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE reads half of a 16 B/lane stream)",
                "kernels": {}}
         for k, (n, v) in sorted(fe.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
             w = wr.get(k, (0, 0.0))[1]
