@@ -217,6 +217,7 @@ void launch_gemm_t(mocr_engine* e, const GemmParams& p0, int split, int ybatch) 
     GemmParams p = p0;
     p.ntn = p.N / BN;
     const int ntm = (p.M + BM - 1) / BM;
+    p.ntm = ntm;
     constexpr int NST = gemm_ring<BM>();
     constexpr int lds = NST * (BM + BN) * 128;
     dim3 grid(ntm * p.ntn, ybatch, split);
@@ -242,6 +243,7 @@ void launch_gemm256_t(mocr_engine* e, const GemmParams& p0) {
     GemmParams p = p0;
     p.ntn = p.N / 128;
     const int ntm = (p.M + 255) / 256;
+    p.ntm = ntm;
     hipLaunchKernelGGL((gemm256_kernel<EPI>), dim3(ntm * p.ntn), dim3(256), 3 * (256 + 128) * 128, e->stream, p);
     HIPCHECK(hipGetLastError());
 }
@@ -264,7 +266,7 @@ struct HeadBatch { int heads = 1; long long a_yoff = 0, w_yoff = 0, o_yoff = 0, 
 template <typename T>
 void gemm(mocr_engine* e, const char* name, const void* A, int lda, const void* W, const float* bias, void* out, int ldo,
           const float* resid, int M, int N, int K, int epi, int tile, int split, long long slab_stride = 0,
-          const float* pos = nullptr, int patches = 0, const HeadBatch* hb = nullptr) {
+          const float* pos = nullptr, int patches = 0, const HeadBatch* hb = nullptr, int group_n = 0) {
     const int kt = 128 / (int)sizeof(T);
     if (N % (tile == 256 ? 128 : tile) || K % (kt * split) || (split > 1 && epi != EPI_SLAB) ||
         (tile == 256 && (sizeof(T) != 2 || split != 1)))
@@ -281,6 +283,8 @@ void gemm(mocr_engine* e, const char* name, const void* A, int lda, const void* 
     p.k_per_split = K / split; p.slab_stride = slab_stride; p.patches = patches;
     static const int ablate = env_int("MOCR_GEMM_ABLATE", 0);
     p.ablate = ablate;
+    static const int group_env = env_int("MOCR_GEMM_GROUPN", -1);
+    p.group_n = group_env >= 0 ? group_env : group_n;
     const double out_b = (epi == EPI_BIAS || epi == EPI_BIAS_GELU) ? sizeof(T) : 4.0;
     const double bytes = ((double)M * K + (double)N * K) * sizeof(T) + (double)M * N * out_b * (epi == EPI_SLAB ? split : 1) +
                          (epi == EPI_BIAS_RESID ? (double)M * N * 4 : 0);
@@ -342,18 +346,20 @@ void run_encoder(mocr_engine* e, const uint8_t* d_gray, int n) {
     // measured (tools/gemm_bench.py): the 256x128 ring kernel wins only where N is large and the
     // epilogue light (QKV); the short-K, fp32-residual GEMMs are better with two 128x128 blocks per
     // CU overlapping each other's epilogue
-    const int ETQ = enc_tile_env ? enc_tile_env : ((sizeof(T) == 2 && M >= 256 * 48) ? 256 : 128);
+    // QKV / FC1 walk the tiles in column groups of 9 / 12 N-tiles (a 1.7 / 2.3 MB weight slice stays in the
+    // XCD's L2): +4 % / +2 % at M = 806,912 (r01); the 256x128 kernel is kept for experiments (MOCR_ENC_TILE=256)
+    const int ETQ = ET;
     gemm<T>(e, "gemm_patch_embed", e->Hb, P * P, w.wpe, w.bpe, e->X, D, nullptr, MPATCH, D, P * P, EPI_PATCH, ET, 1, 0,
             w.pos_enc, NP);
     const int impl = (e->cfg.flags & MOCR_FLAG_SIMPLE_ATTENTION) ? 0 : 1;
     for (int l = 0; l < e->cfg.enc_layers; ++l) {
         const EncLayerW& L = w.enc[l];
         layernorm<T>(e, e->X, L.ln1g, L.ln1b, e->Xn, M);
-        gemm<T>(e, "gemm_enc_qkv", e->Xn, D, L.wqkv, L.bqkv, e->QKV, 3 * D, nullptr, M, 3 * D, D, EPI_BIAS, ETQ, 1);
+        gemm<T>(e, "gemm_enc_qkv", e->Xn, D, L.wqkv, L.bqkv, e->QKV, 3 * D, nullptr, M, 3 * D, D, EPI_BIAS, ETQ, 1, 0, nullptr, 0, nullptr, 9);
         enc_attention<T>(e, e->QKV, e->CTX, n, impl);
         gemm<T>(e, "gemm_enc_oproj", e->CTX, D, L.wo, L.bo, e->X, D, e->X, M, D, D, EPI_BIAS_RESID, ET, 1);
         layernorm<T>(e, e->X, L.ln2g, L.ln2b, e->Xn, M);
-        gemm<T>(e, "gemm_enc_fc1", e->Xn, D, L.w1, L.b1, e->Hb, F, nullptr, M, F, D, EPI_BIAS_GELU, ET, 1);
+        gemm<T>(e, "gemm_enc_fc1", e->Xn, D, L.w1, L.b1, e->Hb, F, nullptr, M, F, D, EPI_BIAS_GELU, ET, 1, 0, nullptr, 0, nullptr, 12);
         gemm<T>(e, "gemm_enc_fc2", e->Hb, F, L.w2, L.b2, e->X, D, e->X, M, D, F, EPI_BIAS_RESID, ET, 1);
     }
     layernorm<T>(e, e->X, w.lnfg, w.lnfb, e->ENC, M);

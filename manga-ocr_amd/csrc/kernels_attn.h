@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void enc_attn_simple_kernel(const T* __restric
 #define ENC_SP 224
 #define ENC_VT_LD 228
 
-__global__ __launch_bounds__(256) void enc_attn_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
+__global__ __launch_bounds__(256, 2) void enc_attn_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
                                                             int H, int ld_qkv, int ld_ctx) {
     constexpr int DH = 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -110,14 +110,18 @@ __global__ __launch_bounds__(256) void enc_attn_mfma_kernel(const bf16_t* __rest
         if (s < ENC_S) kv = *reinterpret_cast<const uint4*>(base + (size_t)s * ld_qkv + D + c * 8);
         *reinterpret_cast<uint4*>(sK + s * 128 + ((c ^ ((s >> 1) & 7)) << 4)) = kv;
     }
-    for (int i = tid; i < ENC_VT_LD * 8; i += 256) {
-        const int s = i >> 3, c = i & 7;
-        uint4 vv = make_uint4(0, 0, 0, 0);
-        if (s < ENC_S) vv = *reinterpret_cast<const uint4*>(base + (size_t)s * ld_qkv + 2 * D + c * 8);
-        const unsigned w[4] = {vv.x, vv.y, vv.z, vv.w};
+    // V^T: a thread takes the same 8 d-values of TWO adjacent keys and writes (key, key+1) pairs as dwords
+    for (int i = tid; i < (ENC_VT_LD / 2) * 8; i += 256) {
+        const int s = (i >> 3) * 2, c = i & 7;
+        uint4 v0 = make_uint4(0, 0, 0, 0), v1 = make_uint4(0, 0, 0, 0);
+        if (s < ENC_S) v0 = *reinterpret_cast<const uint4*>(base + (size_t)s * ld_qkv + 2 * D + c * 8);
+        if (s + 1 < ENC_S) v1 = *reinterpret_cast<const uint4*>(base + (size_t)(s + 1) * ld_qkv + 2 * D + c * 8);
+        const unsigned w0[4] = {v0.x, v0.y, v0.z, v0.w}, w1[4] = {v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-            sVt[(c * 8 + e) * ENC_VT_LD + s] = (bf16_t)((w[e >> 1] >> (16 * (e & 1))) & 0xffff);
+        for (int e = 0; e < 8; ++e) {
+            const unsigned lo = (w0[e >> 1] >> (16 * (e & 1))) & 0xffffu, hi = (w1[e >> 1] >> (16 * (e & 1))) & 0xffffu;
+            *reinterpret_cast<unsigned*>(sVt + (c * 8 + e) * ENC_VT_LD + s) = lo | (hi << 16);
+        }
     }
     __syncthreads();
 
@@ -141,6 +145,7 @@ __global__ __launch_bounds__(256) void enc_attn_mfma_kernel(const bf16_t* __rest
                 const bf16x8 a = *reinterpret_cast<const bf16x8*>(sK + row * 128 + (((2 * s + hh) ^ sw) << 4));
                 st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[s], st[kt], 0, 0, 0);
             }
+            if (kt & 1) __builtin_amdgcn_sched_barrier(0);   // bound the fragment prefetch depth (registers: 2 waves/SIMD)
         }
         // ---- softmax over the 224 keys of this lane's query (112 here, 112 in lane^32)
         float mx = -INFINITY;
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(256) void enc_attn_mfma_kernel(const bf16_t* __rest
         for (int kt = 0; kt < 7; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float e = exp2f(st[kt][r] * c0 - mb);
+                const float e = __builtin_amdgcn_exp2f(st[kt][r] * c0 - mb);   // v_exp_f32; exp2(-inf) = 0 for the padded keys
                 st[kt][r] = e;
                 sum += e;
             }
@@ -189,6 +194,7 @@ __global__ __launch_bounds__(256) void enc_attn_mfma_kernel(const bf16_t* __rest
                     oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cvt.v, pf, oacc[dt], 0, 0, 0);
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (q < ENC_S) {
             const float inv = 1.0f / sum;

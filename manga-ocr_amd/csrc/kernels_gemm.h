@@ -46,7 +46,25 @@ struct GemmParams {
     int patches;           // EPI_PATCH: patches per image (196)
     long long a_yoff, w_yoff, o_yoff, b_yoff;  // element offsets per blockIdx.y (per-head batched GEMMs; EPI_BIAS only)
     int ablate;            // diagnostics only (MOCR_GEMM_ABLATE): 1 no MFMA, 2 no DMA after tile 0, 4 no epilogue
+    int group_n;           // tile order: N-tiles per column group (0 = all: plain row-major tile order)
+    int ntm;               // tiles along M
 };
+
+// Linear tile id -> (tm, tn).  Tiles are ordered column-group by column-group: inside a group of
+// `group_n` N-tiles the order is M-major / N-minor, so the blocks resident on one XCD at a time cover
+// a few M-tiles x group_n N-tiles and the group's weight slice (group_n*BN rows of W) stays in that
+// XCD's 4 MiB L2 while the A row-panels stream through it once per group.
+__device__ __forceinline__ void gemm_tile_of(const GemmParams& p, int bid, int& tm, int& tn) {
+    const int gn = p.group_n > 0 && p.group_n < p.ntn ? p.group_n : p.ntn;
+    const int per_group = p.ntm * gn;
+    int g = bid / per_group;
+    const int ngroups = (p.ntn + gn - 1) / gn;
+    if (g >= ngroups) g = ngroups - 1;
+    const int r = bid - g * per_group;
+    const int gw = min(gn, p.ntn - g * gn);
+    tm = r / gw;
+    tn = g * gn + r - tm * gw;
+}
 
 // Read the fp32 tile back from LDS row by row and apply the fused epilogue; every global access is
 // a 16-byte, row-contiguous access.  NT = threads in the block.
@@ -72,6 +90,14 @@ __device__ __forceinline__ void gemm_epilogue(const float* sC, const GemmParams&
             float* o = reinterpret_cast<float*>(p.out) + (size_t)z * p.slab_stride + (size_t)m * p.ldo + n;
             *reinterpret_cast<float4*>(o) = cv;
         } else if constexpr (EPI == EPI_BIAS) {
+            if constexpr (sizeof(T) == 2) {
+                if (p.ablate & 8) {     // experiment: streaming (non-temporal) output stores
+                    unsigned long long u = (unsigned long long)f2bf(v[0]) | ((unsigned long long)f2bf(v[1]) << 16) |
+                                           ((unsigned long long)f2bf(v[2]) << 32) | ((unsigned long long)f2bf(v[3]) << 48);
+                    __builtin_nontemporal_store(u, reinterpret_cast<unsigned long long*>(reinterpret_cast<T*>(p.out) + (size_t)m * p.ldo + n));
+                    continue;
+                }
+            }
             elem<T>::st4(reinterpret_cast<T*>(p.out) + (size_t)m * p.ldo + n, v);
         } else if constexpr (EPI == EPI_BIAS_GELU) {
 #pragma unroll
@@ -125,7 +151,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
         const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const int tn = bid % p.ntn, tm = bid / p.ntn;
+    int tn, tm;
+    gemm_tile_of(p, bid, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
     const int kbeg = blockIdx.z * p.k_per_split;
     const int nt = p.k_per_split / (128 / (int)sizeof(T));
@@ -281,7 +308,8 @@ __global__ __launch_bounds__(256, 1) void gemm256_kernel(GemmParams p) {
         const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const int tn = bid % p.ntn, tm = bid / p.ntn;
+    int tn, tm;
+    gemm_tile_of(p, bid, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
     const int nt = p.k_per_split / 64;
     const char* Ab = (const char*)p.A + (size_t)m0 * p.lda * 2;

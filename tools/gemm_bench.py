@@ -28,9 +28,21 @@ SHAPES = [  # (name, M, N, K, epi, tile, split)
 ]
 
 
+def enc_shapes(M):
+    return [("enc_qkv t128", M, 2304, 768, "bias", 128, 1), ("enc_qkv t256", M, 2304, 768, "bias", 256, 1),
+            ("enc_oproj t128", M, 768, 768, "resid", 128, 1),
+            ("enc_fc1 t128", M, 3072, 768, "gelu", 128, 1), ("enc_fc1 t256", M, 3072, 768, "gelu", 256, 1),
+            ("enc_fc2 t128", M, 768, 3072, "resid", 128, 1), ("enc_fc2 t256", M, 768, 3072, "resid", 256, 1)]
+
+
 def main():
     eng = Engine(synthetic_weights(0), DEFAULT_SPEC, dtype="bf16", max_batch=8)
-    for name, M, N, K, epi, tile, split in SHAPES:
+    shapes = SHAPES
+    if len(sys.argv) > 1 and sys.argv[1] == "enc":
+        shapes = enc_shapes(int(sys.argv[2]) if len(sys.argv) > 2 else 2048 * 197)
+        if len(sys.argv) > 3:
+            shapes = [s for s in shapes if sys.argv[3] in s[0]]
+    for name, M, N, K, epi, tile, split in shapes:
         Mp = (M + 255) // 256 * 256
         A = (torch.randn(Mp, K, device="cuda") * 0.5).to(torch.bfloat16)
         W = (torch.randn(N, K, device="cuda") * 0.05).to(torch.bfloat16)
@@ -43,7 +55,7 @@ def main():
             eng.op_gemm(A, W, bias, out, resid, M, N, K, EPI[epi], tile=tile, split_k=split)
         eng.profile_enable(True)
         eng.profile_reset()
-        for _ in range(20):
+        for _ in range(20 if M <= 4096 else 5):
             eng.op_gemm(A, W, bias, out, resid, M, N, K, EPI[epi], tile=tile, split_k=split)
         st = eng.profile_get()[0]
         eng.profile_enable(False)
