@@ -192,7 +192,7 @@ def main():
                        "global_batch": world * B, "engine_max_batch": args.max_batch, "lanes": args.lanes, "max_len": L, "decode_steps": T, "parallelism": f"dp{world}",
                        "weights": "synthetic seed 0"},
             "algorithmic_gflop_per_crop": (ENC_FLOPS_PER_CROP + dec_flops_per_crop(T)) / 1e9,
-            "roofline": roof, "cpu_baseline": cpu, "kernels": kernels[:12],
+            "roofline": roof, "cpu_baseline": cpu, "kernels": kernels[:24],
         }
         print(json.dumps(out), flush=True)
     if world > 1:

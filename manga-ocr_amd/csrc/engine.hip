@@ -377,7 +377,10 @@ static int pick_split(int N, int K, int kt, int rows, long long slab_cap_per_row
     // Split K until ~`target` blocks cover the chip, bounded by the K-tiles and by the slab buffer.
     // Every extra slab is an fp32 [rows,N] write plus a read by the consumer, so fat batches
     // (many row tiles) split less.
-    static const int target = env_int("MOCR_DEC_BLOCKS", 150);
+    // measured (r01): 150 for 64..1024 rows; fat batches (>= 2048 rows) gain from one more halving of K
+    // (FC2 at 4096 rows: 48 -> 33 us)
+    static const int target_env = env_int("MOCR_DEC_BLOCKS", 0);
+    const int target = target_env ? target_env : (rows >= 2048 ? 300 : 150);
     const int tile = dec_tile(rows);
     const int tiles = (N / tile) * ((rows + tile - 1) / tile);
     const int ktiles = K / kt;
@@ -506,9 +509,11 @@ void latent_block(mocr_engine* e, bool self, int layer, int n, int t, const void
                   const void* wkT, const void* wv, const float* bv) {
     using T = bf16_t;
     const int D = e->D;
-    gemm<T>(e, "gemm_dec_q", xin, D, wq, bq, e->q_t, D, nullptr, n, D, D, EPI_BIAS, 64, 1);
+    static const int qtile = env_int("MOCR_DEC_QTILE", 64), qttile_env = env_int("MOCR_DEC_QTTILE", 0);
+    const int qttile = qttile_env ? qttile_env : (n >= 1024 ? 128 : 64);      // Qt is output-write bound: fewer, fatter blocks
+    gemm<T>(e, "gemm_dec_q", xin, D, wq, bq, e->q_t, D, nullptr, n, D, D, EPI_BIAS, qtile, 1);
     HeadBatch hq; hq.heads = e->H; hq.a_yoff = 64; hq.w_yoff = 64; hq.o_yoff = D; hq.b_yoff = 0; hq.ldw = D;
-    gemm<T>(e, "gemm_dec_qt", e->q_t, D, wkT, e->w.zero_bias, e->qt, 16 * D, nullptr, n, D, 64, EPI_BIAS, 64, 1, 0, nullptr, 0, &hq);
+    gemm<T>(e, "gemm_dec_qt", e->q_t, D, wkT, e->w.zero_bias, e->qt, 16 * D, nullptr, n, D, 64, EPI_BIAS, qttile, 1, 0, nullptr, 0, &hq);
     latent_attn(e, self, layer, n, self ? t + 1 : e->S);
     HeadBatch hc; hc.heads = e->H; hc.a_yoff = D; hc.w_yoff = (long long)64 * D; hc.o_yoff = 64; hc.b_yoff = 64; hc.ldw = D;
     gemm<T>(e, "gemm_dec_ctx", e->et, 16 * D, wv, bv, e->ctx_t, D, nullptr, n, 64, D, EPI_BIAS, 64, 1, 0, nullptr, 0, &hc);

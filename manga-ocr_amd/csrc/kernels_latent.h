@@ -26,6 +26,7 @@
 #define LAT_TK 32
 #define LAT_TILE_BYTES (LAT_TK * LAT_D * 2)
 #define LAT_NST 3
+#define LAT_OUT_HS (LAT_D * 2 + 16)   // head-row stride of the output staging image
 #define LAT_LDS (LAT_NST * LAT_TILE_BYTES + 4 * 16 * 32 * 4 + 4 * 16 * 32 * 2)
 
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
@@ -125,8 +126,8 @@ __device__ __forceinline__ void lds_read3_b128(uint4* o, unsigned a0, unsigned a
 // vmcnt bookkeeping.  CDNA counts loads, stores and LDS-DMA together, in issue order, so "X has
 // landed" is s_waitcnt vmcnt(number of VMEM instructions this wave issued after X).  The wave keeps
 // that number at run time: `issued` counts its VMEM instructions (12 global_load_lds per tile, 6
-// inline-asm loads per Qt prefetch, 6 global stores per finished row - the row is staged through
-// LDS so that every thread stores exactly 6 x 16 B), and every ring slot remembers the count at
+// inline-asm loads per Qt prefetch, 5 (waves 0, 1) or 4 (waves 2, 3) global stores per finished row - the
+// row is staged through LDS so that the store count is wave-uniform), and every ring slot remembers the count at
 // which its tile was requested.  The Qt loads are inline asm on purpose: an ordinary global load
 // beside LDS-DMA makes hipcc put s_waitcnt vmcnt(0) in front of its first use, which would drain the
 // ring once per tile (cdna_hip_programming.md §5, "Three .s-level traps" (b)).  Because the compiler
@@ -138,24 +139,34 @@ __device__ __forceinline__ void asm_load_q(bf16x8* q, const bf16_t* qrow) {
     for (int s = 0; s < 6; ++s)
         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(q[s]) : "v"(qrow + 32 * s) : "memory");
 }
-// wait until at most `newer` (a multiple of 6) of this wave's VMEM instructions are outstanding
+// wait until at most `newer` of this wave's VMEM instructions are outstanding (exact: rounding down
+// would make the wave wait for DMA of the NEXT tile; vmcnt is a 6-bit immediate, hence the switch)
+#define LAT_VM_CASE(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
 __device__ __forceinline__ void wait_vm_newer(int newer) {
     switch (newer) {
-        case 36: asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); break;
-        case 30: asm volatile("s_waitcnt vmcnt(30)" ::: "memory"); break;
-        case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
-        case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
-        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        LAT_VM_CASE(1) LAT_VM_CASE(2) LAT_VM_CASE(3) LAT_VM_CASE(4) LAT_VM_CASE(5) LAT_VM_CASE(6) LAT_VM_CASE(7)
+        LAT_VM_CASE(8) LAT_VM_CASE(9) LAT_VM_CASE(10) LAT_VM_CASE(11) LAT_VM_CASE(12) LAT_VM_CASE(13) LAT_VM_CASE(14)
+        LAT_VM_CASE(15) LAT_VM_CASE(16) LAT_VM_CASE(17) LAT_VM_CASE(18) LAT_VM_CASE(19) LAT_VM_CASE(20) LAT_VM_CASE(21)
+        LAT_VM_CASE(22) LAT_VM_CASE(23) LAT_VM_CASE(24) LAT_VM_CASE(25) LAT_VM_CASE(26) LAT_VM_CASE(27) LAT_VM_CASE(28)
+        LAT_VM_CASE(29) LAT_VM_CASE(30) LAT_VM_CASE(31) LAT_VM_CASE(32) LAT_VM_CASE(33) LAT_VM_CASE(34) LAT_VM_CASE(35)
+        LAT_VM_CASE(36) LAT_VM_CASE(37) LAT_VM_CASE(38) LAT_VM_CASE(39) LAT_VM_CASE(40) LAT_VM_CASE(41) LAT_VM_CASE(42)
+        LAT_VM_CASE(43) LAT_VM_CASE(44) LAT_VM_CASE(45) LAT_VM_CASE(46) LAT_VM_CASE(47) LAT_VM_CASE(48) LAT_VM_CASE(49)
+        LAT_VM_CASE(50) LAT_VM_CASE(51) LAT_VM_CASE(52) LAT_VM_CASE(53) LAT_VM_CASE(54) LAT_VM_CASE(55) LAT_VM_CASE(56)
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;   // 0, or anything unexpected: drain
     }
 }
+#undef LAT_VM_CASE
 
-// request one 48 KiB tile: 12 DMA instructions per wave (src_off: this lane's 12 source offsets)
-__device__ __forceinline__ void lat_stage(const char* src, char* dst, const unsigned (&src_off)[12], int wave) {
+// request one tile: piece pc = wave + 4i (1 KiB = 64 consecutive 16-byte chunks of the tile image) for
+// pc < np.  A full tile is np = 48 pieces (12 DMA instructions per wave); a sequence's last tile asks only
+// for the pieces that hold its valid keys (src_off: this lane's 12 source offsets).  The branch is
+// wave-uniform; the caller adds lat_pieces_of(np, wave) to its VMEM count.
+__device__ __forceinline__ void lat_stage(const char* src, char* dst, const unsigned (&src_off)[12], int wave, int np) {
 #pragma unroll
-    for (int i = 0; i < 12; ++i) glds16(src + src_off[i], dst + (wave + 4 * i) * 1024);
+    for (int i = 0; i < 12; ++i)
+        if (wave + 4 * i < np) glds16(src + src_off[i], dst + (wave + 4 * i) * 1024);
 }
+__device__ __forceinline__ int lat_pieces_of(int np, int wave) { return (np - wave + 3) >> 2; }   // #i in 0..11 with wave+4i < np (np <= 48)
 
 __global__ __launch_bounds__(256, 1) void latent_attn_kernel(LatentParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -184,11 +195,9 @@ __global__ __launch_bounds__(256, 1) void latent_attn_kernel(LatentParams p) {
 #else
 #define STAMP(k)
 #endif
-    (void)P_heads;
     float* sS = reinterpret_cast<float*>(smem + LAT_NST * LAT_TILE_BYTES);        // [4][16][32] partial scores
     bf16_t* sP = reinterpret_cast<bf16_t*>(sS + 4 * 16 * 32);                      // [16][32] probabilities (1 KiB of a 4 KiB area)
     float* sAl = reinterpret_cast<float*>(sP + 16 * 32);                           // [16] per-head rescale factors, then [16] row sums
-    bf16_t* sO = reinterpret_cast<bf16_t*>(sS);                                    // [8 heads][768] output staging (12 KiB)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     const int nblk = gridDim.x;
@@ -225,9 +234,18 @@ __global__ __launch_bounds__(256, 1) void latent_attn_kernel(LatentParams p) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int s = 0; s < 6; ++s) s_off[6 * j + s] = lat_off(16 * j + l15, 24 * wave + 4 * s + g);
+    // LDS offsets (inside the output staging image) of the 16-byte chunks tid + 256k this thread stores
+    unsigned out_off[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const int idx = tid + 256 * k, h = idx / 96;     // (head, chunk of its 1536-B row); h = 12, 13 for the unused k = 4 of waves 2, 3
+        out_off[k] = (unsigned)(h * LAT_OUT_HS + (idx - 96 * h) * 16);
+    }
     const unsigned smem_base = lds_addr(smem);
     // A operand of the S product: Qt[head = lane&15][192*wave + 32*s + 8*g .. +7]
-    const bf16_t* const q_lane = P_qt + (size_t)l15 * LAT_D + 192 * wave + 8 * g;
+    // (the MFMA rows 12..15 are padding: their lanes re-read heads 0..3 - same cache lines, no extra
+    // traffic - and their results are never stored)
+    const bf16_t* const q_lane = P_qt + (size_t)(l15 < P_heads ? l15 : l15 - P_heads) * LAT_D + 192 * wave + 8 * g;
 #define Q_PTR(row) (q_lane + (size_t)(row) * 16 * LAT_D)
 
     int cr = blockIdx.x;                 // sequence being consumed
@@ -245,14 +263,26 @@ __global__ __launch_bounds__(256, 1) void latent_attn_kernel(LatentParams p) {
 #define ISSUE_NEXT()                                                                                              \
     do {                                                                                                          \
         if (ir < P_rows) {                                                                                        \
+            const int np_ = it == cnt - 1 ? np_last : 48;                                                         \
             lat_stage(reinterpret_cast<const char*>(P_x + (size_t)ir * P_xstride) + (size_t)it * LAT_TILE_BYTES,   \
-                      smem + islot * LAT_TILE_BYTES, src_off, wave);                                              \
-            issued += 12;                                                                                         \
+                      smem + islot * LAT_TILE_BYTES, src_off, wave, np_);                                         \
+            issued += lat_pieces_of(np_, wave);                                                                   \
             if (islot == 0) mk0 = issued; else if (islot == 1) mk1 = issued; else mk2 = issued;                   \
             islot = islot + 1 == LAT_NST ? 0 : islot + 1;                                                         \
             if (++it == cnt) { ir += nblk; it = 0; }                                                              \
         }                                                                                                         \
     } while (0)
+    // pieces of a sequence's last tile that hold valid keys (rows are 96 chunks, pieces 64 chunks)
+    const int np_last = (96 * (L - (cnt - 1) * LAT_TK) + 63) >> 6;
+    // The key rows such a trimmed request leaves alone keep whatever the slot held before: older X rows
+    // (finite; their probabilities are exactly 0) - or, the first time round, whatever the previous kernel
+    // left in LDS, possibly NaN patterns, and 0 x NaN would poison P.X.  So the ring is cleared once.
+    if (np_last < 48) {
+#pragma unroll 4
+        for (int i = tid; i < LAT_NST * LAT_TILE_BYTES / 16; i += 256)
+            *reinterpret_cast<uint4*>(smem + (size_t)i * 16) = make_uint4(0, 0, 0, 0);
+        __syncthreads();
+    }
     ISSUE_NEXT();
     ISSUE_NEXT();
     int slot = 0;
@@ -283,6 +313,7 @@ __global__ __launch_bounds__(256, 1) void latent_attn_kernel(LatentParams p) {
             const char* xt = smem + slot * LAT_TILE_BYTES;
             slot = slot + 1 == LAT_NST ? 0 : slot + 1;
             STAMP(0)   // wait + barrier + DMA issue
+#ifndef MOCR_LAT_NOCOMPUTE   // timing experiment only: DMA ring without any consumer work
 
             // ---- partial scores over this wave's 192 dims: S[head][key], two 16-key sub-tiles.  All twelve
             // operand reads are issued before the first MFMA (left to itself hipcc serialises
@@ -390,9 +421,13 @@ __global__ __launch_bounds__(256, 1) void latent_attn_kernel(LatentParams p) {
                 }
             }
             STAMP(4)   // P read + transposed reads + P.X MFMAs
+#else
+            (void)xt;
+#endif
         }
         // ---- finish the row: normalise, stage through LDS (two halves of 8 heads x 768 bf16 = 12 KiB,
         // the score/probability scratch), store with 3 + 3 full 16-byte accesses per thread
+#ifndef MOCR_LAT_NOEPI       // timing experiment only
         if (l15 == 0) sAl[16 + 4 * g + wave] = l_run;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -405,34 +440,36 @@ __global__ __launch_bounds__(256, 1) void latent_attn_kernel(LatentParams p) {
             inv[0] = 1.0f / __uint_as_float(l4.x); inv[1] = 1.0f / __uint_as_float(l4.y);
             inv[2] = 1.0f / __uint_as_float(l4.z); inv[3] = 1.0f / __uint_as_float(l4.w);
         }
-        char* ob = reinterpret_cast<char*>(P_out + (size_t)cr * 16 * LAT_D);
+        // The ring slot of the tile just consumed is free until the next tile's top-of-loop barrier (its refill
+        // is requested after that barrier), so all 12 heads x 768 bf16 are staged there in ONE pass: head rows
+        // LAT_OUT_HS bytes apart (1536 + 16: the three lane groups of a wave then write different banks).
+        char* const stg = smem + islot * LAT_TILE_BYTES;
+        if (g < 3) {                                // lane group 3 holds the padding heads 12..15
+            char* const wb = stg + (4 * g) * LAT_OUT_HS + (192 * wave + l15) * 2;
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();           // scratch free: every wave is past its last reads
-            asm volatile("" ::: "memory");
-            if ((g >> 1) == half) {                 // lane groups g = 2*half, 2*half+1 hold heads 8*half .. 8*half+7
+            for (int dt = 0; dt < 12; ++dt)
 #pragma unroll
-                for (int dt = 0; dt < 12; ++dt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        sO[(4 * (g & 1) + r) * LAT_D + 192 * wave + 16 * dt + l15] = f2bf(cacc[dt][r] * inv[r]);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            {
-                // 768 chunks of 16 B = 8 heads x 768 x 2 B: thread tid moves chunks tid, tid+256, tid+512
-                uint4 v[3];
-                const unsigned so_a = lds_addr(sO) + tid * 16;
-                lds_read3_b128(v, so_a, so_a + 4096, so_a + 8192);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int k = 0; k < 3; ++k)
-                    *reinterpret_cast<uint4*>(ob + half * (8 * LAT_D * 2) + (tid + 256 * k) * 16) = v[k];
-            }
+                for (int r = 0; r < 4; ++r)
+                    *reinterpret_cast<bf16_t*>(wb + r * LAT_OUT_HS + dt * 32) = f2bf(cacc[dt][r] * inv[r]);
         }
-        issued += 6;                                  // the 3 + 3 stores above
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        {
+            // 1152 chunks of 16 B = 12 heads x 1536 B, contiguous in the output: thread tid moves chunks
+            // tid + 256k, k = 0..3, and chunk tid + 1024 from waves 0 and 1 only (wave-uniform store count)
+            char* ob = reinterpret_cast<char*>(P_out + (size_t)cr * 16 * LAT_D);
+            uint4 v[5];
+            const unsigned sa = lds_addr(stg);
+            lds_read3_b128(v, sa + out_off[0], sa + out_off[1], sa + out_off[2]);
+            lds_read2_b128(v + 3, sa + out_off[3], sa + out_off[4]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 5; ++k)
+                if (k < 4 || wave < 2) *reinterpret_cast<uint4*>(ob + (tid + 256 * k) * 16) = v[k];
+        }
+        issued += wave < 2 ? 5 : 4;                   // the stores above
+#endif
         // ---- the next row's Qt: prove the prefetch landed, then (and only then) copy it.  With >= 3 tiles
         // the wait for tile 2 (requested after the prefetch) already proved it; shorter rows wait here
         // (at most 2 tiles + 6 stores = 30 younger instructions).
