@@ -133,6 +133,7 @@ struct mocr_engine : LaneCtx {
     Weights w;
     // geometry
     int S = 0, G = 0, D = 0, H = 0, F = 0, V = 0, Bp = 0, Mp = 0, NCKV = 0;
+    int num_cus = 256;           // compute units, rounded down to a multiple of 8 (persistent grids: equal share per XCD)
     size_t esz = 2;
     std::vector<Lane> lanes;
     std::vector<Job> pending;
@@ -259,7 +260,36 @@ void launch_gemm256(mocr_engine* e, const GemmParams& p, int epi) {
     }
 }
 
-// A [M,K] (lda), W [N,K] (ldw=K), out (ldo).  tile: 64, 128, or 256 (= the 256x128 bf16 kernel).
+template <int EPI, int WN>
+void launch_gemm_wide_t(mocr_engine* e, const GemmParams& p0) {
+    GemmParams p = p0;
+    p.ntn = p.N / (64 * WN);
+    const int ntm = (p.M + 255) / 256;
+    p.ntm = ntm;
+    // persistent: one (256x256) or two (256x128) blocks per CU, a multiple of 8 so that every XCD gets the same count
+    const int ntiles = ntm * p.ntn;
+    // Default: one tile per block (grid = tiles, rounded up to 8: an empty block returns at once).  With
+    // MOCR_GEMM_PERSIST=1 the grid is one (256x256) or two (256x128) blocks per CU and each block walks its tiles:
+    // measured +2 % / -12 % at M = 806,912 (r01) - these GEMMs are bound by the L2's bandwidth, writes included,
+    // not by the store drain at block end - so it stays an experiment.
+    static const int persist = env_int("MOCR_GEMM_PERSIST", 0);
+    const int full = (ntiles + 7) / 8 * 8;
+    const int grid = persist ? std::min(e->num_cus * (WN == 2 ? 2 : 1), full) : full;
+    hipLaunchKernelGGL((gemm_wide_kernel<EPI, WN>), dim3(grid), dim3(128 * WN), 3 * (256 + 64 * WN) * 64, e->stream, p);
+    HIPCHECK(hipGetLastError());
+}
+
+template <int WN>
+void launch_gemm_wide(mocr_engine* e, const GemmParams& p, int epi) {
+    switch (epi) {
+        case EPI_BIAS: launch_gemm_wide_t<EPI_BIAS, WN>(e, p); break;
+        case EPI_BIAS_GELU: launch_gemm_wide_t<EPI_BIAS_GELU, WN>(e, p); break;
+        case EPI_BIAS_RESID: launch_gemm_wide_t<EPI_BIAS_RESID, WN>(e, p); break;
+        default: throw ArgError{"wide gemm: unsupported epilogue", MOCR_ERR_ARG};
+    }
+}
+
+// A [M,K] (lda), W [N,K] (ldw=K), out (ldo).  tile: 64, 128, 256 (256x128, 3-stage), 512 (the "wide" 256x128 kernel) or 1024 (wide, 256x256, 8 waves) (= the 256x128 bf16 kernel).
 // split > 1 only with EPI_SLAB.
 struct HeadBatch { int heads = 1; long long a_yoff = 0, w_yoff = 0, o_yoff = 0, b_yoff = 0; int ldw = 0; };
 
@@ -268,15 +298,15 @@ void gemm(mocr_engine* e, const char* name, const void* A, int lda, const void* 
           const float* resid, int M, int N, int K, int epi, int tile, int split, long long slab_stride = 0,
           const float* pos = nullptr, int patches = 0, const HeadBatch* hb = nullptr, int group_n = 0) {
     const int kt = 128 / (int)sizeof(T);
-    if (N % (tile == 256 ? 128 : tile) || K % (kt * split) || (split > 1 && epi != EPI_SLAB) ||
-        (tile == 256 && (sizeof(T) != 2 || split != 1)))
+    if (N % (tile == 1024 ? 256 : tile >= 256 ? 128 : tile) || K % (kt * split) || (split > 1 && epi != EPI_SLAB) ||
+        (tile >= 256 && (sizeof(T) != 2 || split != 1)))
         throw ArgError{std::string("gemm shape not tileable: ") + name, MOCR_ERR_ARG};
     GemmParams p{};
     p.A = A; p.W = W; p.bias = bias; p.out = out; p.resid = resid; p.pos = pos;
     p.M = M; p.N = N; p.lda = lda; p.ldw = K; p.ldo = ldo;
     int ybatch = 1;
     if (hb) {
-        if (epi != EPI_BIAS || tile == 256) throw ArgError{"per-head batched GEMM needs EPI_BIAS on the 64/128 kernel", MOCR_ERR_ARG};
+        if (epi != EPI_BIAS || tile >= 256) throw ArgError{"per-head batched GEMM needs EPI_BIAS on the 64/128 kernel", MOCR_ERR_ARG};
         ybatch = hb->heads; p.a_yoff = hb->a_yoff; p.w_yoff = hb->w_yoff; p.o_yoff = hb->o_yoff; p.b_yoff = hb->b_yoff;
         if (hb->ldw) p.ldw = hb->ldw;
     }
@@ -289,10 +319,12 @@ void gemm(mocr_engine* e, const char* name, const void* A, int lda, const void* 
     const double bytes = ((double)M * K + (double)N * K) * sizeof(T) + (double)M * N * out_b * (epi == EPI_SLAB ? split : 1) +
                          (epi == EPI_BIAS_RESID ? (double)M * N * 4 : 0);
     ProfScope ps(e, name, 2.0 * M * N * K * ybatch, bytes * ybatch);
-    if (tile == 256) launch_gemm256(e, p, epi);
+    if (tile == 1024) launch_gemm_wide<4>(e, p, epi);
+    else if (tile == 512) launch_gemm_wide<2>(e, p, epi);
+    else if (tile == 256) launch_gemm256(e, p, epi);
     else if (tile == 128) launch_gemm_epi<T, 128, 128>(e, p, epi, split, ybatch);
     else if (tile == 64) launch_gemm_epi<T, 64, 64>(e, p, epi, split, ybatch);
-    else throw ArgError{"gemm tile must be 64, 128 or 256", MOCR_ERR_ARG};
+    else throw ArgError{"gemm tile must be 64, 128, 256, 512 or 1024", MOCR_ERR_ARG};
 }
 
 // ---------------------------------------------------------------------------------------- encoder
@@ -340,15 +372,20 @@ void run_encoder(mocr_engine* e, const uint8_t* d_gray, int n) {
         hipLaunchKernelGGL(cls_rows_kernel, dim3((n * D + 255) / 256), dim3(256), 0, e->stream, w.cls, w.pos_enc, e->X, n, S, D);
         HIPCHECK(hipGetLastError());
     }
-    // big-tile kernel once there are enough 256-row tiles to fill the chip (bf16 only)
+    // MOCR_ENC_TILE forces one tile code for the layer GEMMs (experiments); the patch embedding has its own epilogue
+    // and stays on the 128x128 kernel unless a tile code that supports it (64/128/256) is forced
     static const int enc_tile_env = env_int("MOCR_ENC_TILE", 0);
-    const int ET = enc_tile_env ? enc_tile_env : 128;
-    // measured (tools/gemm_bench.py): the 256x128 ring kernel wins only where N is large and the
-    // epilogue light (QKV); the short-K, fp32-residual GEMMs are better with two 128x128 blocks per
-    // CU overlapping each other's epilogue
-    // QKV / FC1 walk the tiles in column groups of 9 / 12 N-tiles (a 1.7 / 2.3 MB weight slice stays in the
-    // XCD's L2): +4 % / +2 % at M = 806,912 (r01); the 256x128 kernel is kept for experiments (MOCR_ENC_TILE=256)
-    const int ETQ = ET;
+    const int ET = (enc_tile_env && enc_tile_env <= 256) ? enc_tile_env : 128;
+    // The 128x128 kernel walks QKV / FC1 in column groups of 9 / 12 N-tiles (a 1.7 / 2.3 MB weight slice stays in
+    // the XCD's L2): +4 % / +2 % at M = 806,912 (r01).
+    // Layer GEMMs: the 256x256 "wide" kernel (tile code 1024) once it fills the chip about three times over
+    // (+12..15 % at M = 806,912, +10..20 % at M = 100,864; even at 12,608 rows), else the 128x128 kernel
+    auto layer_tile = [&](int N) {
+        if (enc_tile_env) return enc_tile_env;
+        const long long tiles = (long long)((M + 255) / 256) * (N / 256);
+        return (sizeof(T) == 2 && tiles >= 3LL * e->num_cus) ? 1024 : 128;
+    };
+    const int ETQ = layer_tile(3 * D), ETO = layer_tile(D), ET1 = layer_tile(F);
     gemm<T>(e, "gemm_patch_embed", e->Hb, P * P, w.wpe, w.bpe, e->X, D, nullptr, MPATCH, D, P * P, EPI_PATCH, ET, 1, 0,
             w.pos_enc, NP);
     const int impl = (e->cfg.flags & MOCR_FLAG_SIMPLE_ATTENTION) ? 0 : 1;
@@ -357,10 +394,10 @@ void run_encoder(mocr_engine* e, const uint8_t* d_gray, int n) {
         layernorm<T>(e, e->X, L.ln1g, L.ln1b, e->Xn, M);
         gemm<T>(e, "gemm_enc_qkv", e->Xn, D, L.wqkv, L.bqkv, e->QKV, 3 * D, nullptr, M, 3 * D, D, EPI_BIAS, ETQ, 1, 0, nullptr, 0, nullptr, 9);
         enc_attention<T>(e, e->QKV, e->CTX, n, impl);
-        gemm<T>(e, "gemm_enc_oproj", e->CTX, D, L.wo, L.bo, e->X, D, e->X, M, D, D, EPI_BIAS_RESID, ET, 1);
+        gemm<T>(e, "gemm_enc_oproj", e->CTX, D, L.wo, L.bo, e->X, D, e->X, M, D, D, EPI_BIAS_RESID, ETO, 1);
         layernorm<T>(e, e->X, L.ln2g, L.ln2b, e->Xn, M);
-        gemm<T>(e, "gemm_enc_fc1", e->Xn, D, L.w1, L.b1, e->Hb, F, nullptr, M, F, D, EPI_BIAS_GELU, ET, 1, 0, nullptr, 0, nullptr, 12);
-        gemm<T>(e, "gemm_enc_fc2", e->Hb, F, L.w2, L.b2, e->X, D, e->X, M, D, F, EPI_BIAS_RESID, ET, 1);
+        gemm<T>(e, "gemm_enc_fc1", e->Xn, D, L.w1, L.b1, e->Hb, F, nullptr, M, F, D, EPI_BIAS_GELU, ET1, 1, 0, nullptr, 0, nullptr, 12);
+        gemm<T>(e, "gemm_enc_fc2", e->Hb, F, L.w2, L.b2, e->X, D, e->X, M, D, F, EPI_BIAS_RESID, ETO, 1);
     }
     layernorm<T>(e, e->X, w.lnfg, w.lnfb, e->ENC, M);
 }
@@ -595,6 +632,12 @@ template <typename T> void init_kernel_attrs() {
     set_max_lds(enc_attn_simple_kernel<T>, (200 * 65 + 200 * 64 + 4 * 64 + 4 * 256) * 4);
     set_max_lds(enc_attn_mfma_kernel, ENC_SP * 128 + 64 * ENC_VT_LD * 2);
     constexpr int l256 = 3 * (256 + 128) * 128;
+    set_max_lds(gemm_wide_kernel<EPI_BIAS, 2>, 3 * (256 + 128) * 64);
+    set_max_lds(gemm_wide_kernel<EPI_BIAS_GELU, 2>, 3 * (256 + 128) * 64);
+    set_max_lds(gemm_wide_kernel<EPI_BIAS_RESID, 2>, 3 * (256 + 128) * 64);
+    set_max_lds(gemm_wide_kernel<EPI_BIAS, 4>, 3 * (256 + 256) * 64);
+    set_max_lds(gemm_wide_kernel<EPI_BIAS_GELU, 4>, 3 * (256 + 256) * 64);
+    set_max_lds(gemm_wide_kernel<EPI_BIAS_RESID, 4>, 3 * (256 + 256) * 64);
     set_max_lds(gemm256_kernel<EPI_BIAS>, l256);
     set_max_lds(gemm256_kernel<EPI_BIAS_GELU>, l256);
     set_max_lds(gemm256_kernel<EPI_BIAS_RESID>, l256);
@@ -1052,6 +1095,11 @@ int mocr_create(const mocr_config* cfg, mocr_engine** out) {
         HIPCHECK(hipGetDeviceCount(&ndev));
         if (ndev <= 0) throw ArgError{"no HIP device visible: the Manga-OCR engine needs a GPU", MOCR_ERR_HIP};
         HIPCHECK(hipSetDevice(cfg->device));
+        {
+            int cus = 0;
+            HIPCHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device));
+            e->num_cus = cus >= 8 ? cus / 8 * 8 : 8;
+        }
         allocate_lanes(e);
     });
     if (rc != MOCR_OK) {

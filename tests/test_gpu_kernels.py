@@ -57,12 +57,16 @@ def test_gemm_epilogues(dtype, tile, M, N, K, epi):
     assert err <= tol
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (512, 768, 768), (700, 2304, 768), (1000, 768, 3072), (256, 768, 256)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 768), (700, 2304, 768), (1000, 768, 3072), (256, 768, 256)])
 @pytest.mark.parametrize("epi", [EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_BIAS_F32])
-def test_gemm_256x128_three_stage_ring(M, N, K, epi):
-    """The big-tile encoder kernel (bf16 only): K from 1 to 48 K-tiles exercises the ring's
-    prologue, steady state (counted vmcnt) and drain; M not a multiple of 256 exercises the
-    row guard."""
+@pytest.mark.parametrize("tile", [256, 512, 1024])
+def test_gemm_256x128_three_stage_ring(M, N, K, epi, tile):
+    """The big-tile encoder kernels (bf16 only; 256 = 64-deep K-tiles, epilogue through LDS; 512 = the
+    "wide" kernel: 32-deep K-tiles, two blocks per CU, epilogue from the registers): K from 1 to 96
+    K-tiles exercises the ring's prologue, steady state (counted vmcnt) and drain; M not a multiple of
+    256 exercises the row guard."""
+    if tile >= 512 and epi == EPI_BIAS_F32:
+        pytest.skip("the wide kernel has the encoder layers' epilogues only")
     eng = engine("bf16")
     rs = np.random.RandomState(M + N + K + epi)
     Mp = (M + 255) // 256 * 256
@@ -80,11 +84,11 @@ def test_gemm_256x128_three_stage_ring(M, N, K, epi):
     dR = torch.from_numpy(resid).cuda() if epi == EPI_BIAS_RESID else None
     dA, dW, dB = _dev(A, "bf16"), _dev(W, "bf16"), torch.from_numpy(bias).cuda()
     torch.cuda.synchronize()
-    eng.op_gemm(dA, dW, dB, dO, dR, M, N, K, epi, tile=256, split_k=1)
+    eng.op_gemm(dA, dW, dB, dO, dR, M, N, K, epi, tile=tile, split_k=1)
     got = dO.float().cpu().numpy().astype(np.float64)
     err = np.abs(got - ref).max() / np.abs(ref).max()
     tol = 1e-5 if out_f32 else 6e-3
-    report(f"gemm256 M{M} N{N} K{K} epi{epi}: max rel err {err:.3e} (tol {tol:.1e})")
+    report(f"gemm tile{tile} M{M} N{N} K{K} epi{epi}: max rel err {err:.3e} (tol {tol:.1e})")
     assert np.isfinite(got).all() and err <= tol
 
 

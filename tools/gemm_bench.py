@@ -29,10 +29,12 @@ SHAPES = [  # (name, M, N, K, epi, tile, split)
 
 
 def enc_shapes(M):
-    return [("enc_qkv t128", M, 2304, 768, "bias", 128, 1), ("enc_qkv t256", M, 2304, 768, "bias", 256, 1),
-            ("enc_oproj t128", M, 768, 768, "resid", 128, 1),
-            ("enc_fc1 t128", M, 3072, 768, "gelu", 128, 1), ("enc_fc1 t256", M, 3072, 768, "gelu", 256, 1),
-            ("enc_fc2 t128", M, 768, 3072, "resid", 128, 1), ("enc_fc2 t256", M, 768, 3072, "resid", 256, 1)]
+    out = []
+    for name, N, K, epi in (("enc_qkv", 2304, 768, "bias"), ("enc_oproj", 768, 768, "resid"), ("enc_fc1", 3072, 768, "gelu"),
+                            ("enc_fc2", 768, 3072, "resid")):
+        for tile in (128, 256, 512, 1024):
+            out.append((f"{name} t{tile}", M, N, K, epi, tile, 1))
+    return out
 
 
 def main():
