@@ -534,7 +534,7 @@ void latent_attn(mocr_engine* e, bool self, int layer, int n, int approx_len) {
         p.fixed_len = e->S;
     }
     ProfScope ps(e, self ? "lat_attn_self" : "lat_attn_cross", 4.0 * n * 16 * approx_len * e->D,
-                 (double)n * approx_len * e->D * 2 + 2.0 * n * 16 * e->D * 2);
+                 (double)n * approx_len * e->D * 2 + 2.0 * n * e->H * e->D * 2);     // keys + Qt in + Et out (12 heads)
     static const int lat_blocks = env_int("MOCR_LAT_BLOCKS", 256);
     hipLaunchKernelGGL(latent_attn_kernel, dim3(std::min(n, lat_blocks)), dim3(256), LAT_LDS, e->stream, p);
     HIPCHECK(hipGetLastError());
