@@ -95,12 +95,31 @@ int mocr_commit_weights(mocr_engine* e);
  * luminance plane the recogniser's convert('L') would produce, 3 = RGB as handed over at
  * src/ui/main_window.py:9800; converted on the device with Pillow's fixed-point formula),
  * row_stride bytes between rows, image_stride bytes between crops.  h and w must equal
- * image_size (the PIL-exact resize of other sizes is done by the caller in this version).
+ * image_size (crops of other sizes: mocr_recognize_images below).
  * out_ids [n, max_len] int32, out_len [n] int32.  Blocking; thread-safe (calls from
  * several threads are serialised per engine).  n may exceed max_batch. */
 int mocr_recognize(mocr_engine* e, const uint8_t* images, int32_t n, int32_t h, int32_t w,
                    int64_t row_stride, int64_t image_stride, int32_t channels,
                    int32_t* out_ids, int32_t* out_len);
+
+/* THE HOT PATH from crops of ANY size (BASELINE configs[4]'s variable-resolution crops).
+ * The device does what the reference's recogniser and image processor do in front of the encoder:
+ * img.convert('L') [.convert('RGB')] and resize((224,224), BILINEAR) (MangaOcr.__call__, SURVEY row a10;
+ * TF/models/vit/image_processing_pil_vit.py:20-27, TF/image_processing_backends.py:521-570 -> Pillow's
+ * ImagingResample) - in Pillow's own fixed-point arithmetic, i.e. bit-exact with the CPU path.
+ * One descriptor per crop: host pointer, size, bytes between rows, channels (1 = L, 3 = RGB as handed over at
+ * src/ui/main_window.py:9800).  The callee neither keeps nor modifies the pixels. */
+typedef struct mocr_image {
+    const uint8_t* data;
+    int32_t height, width;
+    int64_t row_stride;
+    int32_t channels;
+} mocr_image;
+/* out_ids [n, max_len] int32, out_len [n] int32 (host).  Blocking, thread-safe; n may exceed max_batch. */
+int mocr_recognize_images(mocr_engine* e, const mocr_image* images, int32_t n, int32_t* out_ids, int32_t* out_len);
+/* Preprocessing only (test hook): out_gray [n, image_size, image_size] uint8 (host) = the plane the encoder sees
+ * in each of its three equal input channels before the 1/255 and (x - 0.5)/0.5 scaling. */
+int mocr_preprocess(mocr_engine* e, const mocr_image* images, int32_t n, uint8_t* out_gray);
 
 /* THE HOT PATH (device buffers, asynchronous): submits one batch.  d_gray is a device pointer to
  * n contiguous image_size x image_size uint8 luminance planes, d_out_ids / d_out_len device

@@ -29,6 +29,7 @@
 #include "kernels_decode.h"
 #include "kernels_gemm.h"
 #include "kernels_latent.h"
+#include "preprocess.h"
 #include "kernels_misc.h"
 
 namespace {
@@ -141,6 +142,20 @@ struct mocr_engine : LaneCtx {
     std::map<std::tuple<int, int, int, int>, hipGraphExec_t> graphs;
     void bind(int i) { static_cast<LaneCtx&>(*this) = lanes[i].ctx; }
     void unbind(int i) { lanes[i].ctx = static_cast<LaneCtx&>(*this); }
+    // device preprocessing (preprocess.h): resample tables per input size, grow-only scratch
+    std::map<int, ResampleTable> rs_tables;
+    struct Scratch { void* p = nullptr; size_t cap = 0; };
+    Scratch rs_src, rs_tmp, rs_desc, rs_coef, rs_bounds, rs_gray;
+    void* grow(Scratch& s, size_t bytes) {
+        if (bytes > s.cap) {
+            if (s.p) HIPCHECK(hipFree(s.p));
+            s.p = nullptr; s.cap = 0;
+            const size_t cap = std::max<size_t>(bytes + bytes / 2, 4096);
+            HIPCHECK(hipMalloc(&s.p, cap));
+            s.cap = cap;
+        }
+        return s.p;
+    }
     // profiling
     bool prof_on = false;
     std::vector<std::string> knames;
@@ -1118,6 +1133,8 @@ void mocr_destroy(mocr_engine* e) {
         if (L.ctx.stream) (void)hipStreamSynchronize(L.ctx.stream);
     for (auto& r : e->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
+    for (auto* sc : {&e->rs_src, &e->rs_tmp, &e->rs_desc, &e->rs_coef, &e->rs_bounds, &e->rs_gray})
+        if (sc->p) (void)hipFree(sc->p);
     for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
     for (void* p : e->allocs) (void)hipFree(p);
     for (auto& L : e->lanes) {
@@ -1212,6 +1229,116 @@ int mocr_recognize_gray_host(mocr_engine* e, const uint8_t* gray, int32_t n, int
         HIPCHECK(hipSetDevice(e->cfg.device));
         const int IMG = e->cfg.image_size;
         recognize_host_chunks(e, gray, n, IMG, IMG, IMG, (int64_t)IMG * IMG, 1, max_len_override, out_ids, out_len);
+    });
+}
+
+// L conversion + Pillow-exact BILINEAR resize of n host images (any sizes) into d_out [n][IMG][IMG] u8 on the
+// device; synchronous (lane 0's stream).
+static void preprocess_images(mocr_engine* e, const mocr_image* imgs, int n, uint8_t* d_out) {
+    const int IMG = e->cfg.image_size;
+    if (n > 4096) {          // bounded scratch and grid.y: 4096 crops per pass
+        for (int b = 0; b < n; b += 4096) preprocess_images(e, imgs + b, std::min(4096, n - b), d_out + (size_t)b * IMG * IMG);
+        return;
+    }
+    if (IMG != 224) throw ArgError{"device preprocessing is instantiated for image_size 224", MOCR_ERR_UNSUPPORTED};
+    std::vector<ResizeDesc> descs(n);
+    std::vector<int> coef, bounds;
+    std::map<int, std::pair<int, int>> placed;        // input size -> (coef offset, bounds offset) in this call's buffers
+    size_t src_bytes = 0, tmp_bytes = 0;
+    int max_h = 0;
+    auto place = [&](int in_size, int& k_off, int& b_off, int& ks) {
+        if (in_size == IMG) { k_off = b_off = ks = 0; return; }           // Pillow skips a pass whose size is unchanged
+        auto it = e->rs_tables.find(in_size);
+        if (it == e->rs_tables.end()) it = e->rs_tables.emplace(in_size, make_resample_table(in_size, IMG)).first;
+        const ResampleTable& t = it->second;
+        auto pl = placed.find(in_size);
+        if (pl == placed.end()) {
+            pl = placed.emplace(in_size, std::make_pair((int)coef.size(), (int)bounds.size())).first;
+            coef.insert(coef.end(), t.kk.begin(), t.kk.end());
+            bounds.insert(bounds.end(), t.bounds.begin(), t.bounds.end());
+        }
+        k_off = pl->second.first; b_off = pl->second.second; ks = t.ksize;
+    };
+    for (int i = 0; i < n; ++i) {
+        const mocr_image& im = imgs[i];
+        if (!im.data || im.height < 1 || im.width < 1 || im.height > 16384 || im.width > 16384 || (im.channels != 1 && im.channels != 3) ||
+            im.row_stride < (int64_t)im.width * im.channels)
+            throw ArgError{"bad image descriptor (channels must be 1 = L or 3 = RGB)", MOCR_ERR_ARG};
+        ResizeDesc& d = descs[i];
+        d.h = im.height; d.w = im.width; d.channels = im.channels; d.stride = im.width * im.channels;
+        d.src_off = (long long)src_bytes; d.tmp_off = (long long)tmp_bytes;
+        src_bytes += (size_t)d.h * d.stride;
+        tmp_bytes += (size_t)d.h * IMG;
+        place(d.w, d.kx_off, d.bx_off, d.ksx);
+        place(d.h, d.ky_off, d.by_off, d.ksy);
+        max_h = std::max(max_h, d.h);
+    }
+    // pack the pixel rows (drops the callers' row padding), one copy per buffer
+    std::vector<uint8_t> packed(src_bytes);
+    for (int i = 0; i < n; ++i)
+        for (int y = 0; y < descs[i].h; ++y)
+            memcpy(packed.data() + descs[i].src_off + (size_t)y * descs[i].stride, imgs[i].data + (size_t)y * imgs[i].row_stride,
+                   (size_t)descs[i].stride);
+    uint8_t* d_src = (uint8_t*)e->grow(e->rs_src, src_bytes);
+    uint8_t* d_tmp = (uint8_t*)e->grow(e->rs_tmp, tmp_bytes);
+    ResizeDesc* d_desc = (ResizeDesc*)e->grow(e->rs_desc, descs.size() * sizeof(ResizeDesc));
+    int* d_coef = (int*)e->grow(e->rs_coef, std::max<size_t>(coef.size(), 1) * sizeof(int));
+    int* d_bounds = (int*)e->grow(e->rs_bounds, std::max<size_t>(bounds.size(), 1) * sizeof(int));
+    HIPCHECK(hipMemcpyAsync(d_src, packed.data(), src_bytes, hipMemcpyHostToDevice, e->stream));
+    HIPCHECK(hipMemcpyAsync(d_desc, descs.data(), descs.size() * sizeof(ResizeDesc), hipMemcpyHostToDevice, e->stream));
+    if (!coef.empty()) HIPCHECK(hipMemcpyAsync(d_coef, coef.data(), coef.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    if (!bounds.empty()) HIPCHECK(hipMemcpyAsync(d_bounds, bounds.data(), bounds.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    constexpr int ROWS = 8;
+    {
+        ProfScope ps(e, "resize_h", 0, (double)src_bytes + (double)tmp_bytes);
+        hipLaunchKernelGGL((resize_h_kernel<224, ROWS>), dim3((max_h + ROWS - 1) / ROWS, n), dim3(256), 0, e->stream, d_src, d_desc, d_coef,
+                           d_bounds, d_tmp);
+        HIPCHECK(hipGetLastError());
+    }
+    {
+        ProfScope ps(e, "resize_v", 0, (double)tmp_bytes + (double)n * IMG * IMG);
+        hipLaunchKernelGGL((resize_v_kernel<224, ROWS>), dim3(224 / ROWS, n), dim3(256), 0, e->stream, d_tmp, d_desc, d_coef, d_bounds, d_out);
+        HIPCHECK(hipGetLastError());
+    }
+    HIPCHECK(hipStreamSynchronize(e->stream));       // `packed` and the descriptors are host temporaries
+}
+
+int mocr_preprocess(mocr_engine* e, const mocr_image* images, int32_t n, uint8_t* out_gray) {
+    return guarded(e, [&] {
+        std::lock_guard<std::mutex> lk(e->mu);
+        if (!images || !out_gray || n < 1) throw ArgError{"bad argument", MOCR_ERR_ARG};
+        HIPCHECK(hipSetDevice(e->cfg.device));
+        drive(e);
+        e->bind(0);
+        const size_t plane = (size_t)e->cfg.image_size * e->cfg.image_size;
+        uint8_t* d_gray = (uint8_t*)e->grow(e->rs_gray, (size_t)n * plane);
+        preprocess_images(e, images, n, d_gray);
+        HIPCHECK(hipMemcpy(out_gray, d_gray, (size_t)n * plane, hipMemcpyDeviceToHost));
+        e->unbind(0);
+    });
+}
+
+int mocr_recognize_images(mocr_engine* e, const mocr_image* images, int32_t n, int32_t* out_ids, int32_t* out_len) {
+    return guarded(e, [&] {
+        std::lock_guard<std::mutex> lk(e->mu);
+        require_ready(e, n, false);
+        if (!images || !out_ids || !out_len) throw ArgError{"null pointer", MOCR_ERR_ARG};
+        HIPCHECK(hipSetDevice(e->cfg.device));
+        drive(e);
+        const size_t plane = (size_t)e->cfg.image_size * e->cfg.image_size;
+        e->bind(0);
+        uint8_t* d_gray = (uint8_t*)e->grow(e->rs_gray, (size_t)n * plane);
+        preprocess_images(e, images, n, d_gray);
+        e->unbind(0);
+        for (int base = 0; base < n; base += e->cfg.max_batch) {
+            Job j;
+            j.src = d_gray + (size_t)base * plane; j.src_host = false; j.channels = 1;
+            j.row_stride = e->cfg.image_size; j.image_stride = (int64_t)plane;
+            j.n = std::min(e->cfg.max_batch, n - base); j.max_len = e->cfg.max_len;
+            j.out_ids = out_ids + (size_t)base * e->cfg.max_len; j.out_len = out_len + base; j.out_host = true;
+            e->pending.push_back(j);
+        }
+        drive(e);
     });
 }
 

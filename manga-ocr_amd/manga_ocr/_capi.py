@@ -29,6 +29,12 @@ class MocrKernelStat(C.Structure):
 
 # every symbol include/mocr.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
+class MocrImage(C.Structure):
+    """include/mocr.h: mocr_image"""
+    _fields_ = [("data", C.c_void_p), ("height", C.c_int32), ("width", C.c_int32), ("row_stride", C.c_int64),
+                ("channels", C.c_int32)]
+
+
 SYMBOLS = {
     "mocr_abi_version": (C.c_int, []),
     "mocr_create": (C.c_int, [C.POINTER(MocrConfig), C.POINTER(_P)]),
@@ -37,6 +43,8 @@ SYMBOLS = {
     "mocr_set_tensor": (C.c_int, [_P, C.c_char_p, _P, C.POINTER(C.c_int64), C.c_int32]),
     "mocr_commit_weights": (C.c_int, [_P]),
     "mocr_recognize": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int32, _P, _P]),
+    "mocr_recognize_images": (C.c_int, [_P, C.POINTER(MocrImage), C.c_int32, _P, _P]),
+    "mocr_preprocess": (C.c_int, [_P, C.POINTER(MocrImage), C.c_int32, _P]),
     "mocr_recognize_device": (C.c_int, [_P, _P, C.c_int32, _P, _P]),
     "mocr_synchronize": (C.c_int, [_P]),
     "mocr_stream": (_P, [_P]),

@@ -96,6 +96,42 @@ class Engine:
         self._check(self.lib.mocr_recognize(self._h, _ptr(a), n, h, w, w * ch, h * w * ch, ch, _ptr(ids), _ptr(lens)))
         return ids, lens
 
+    def _image_descs(self, images):
+        """numpy uint8 [h,w] (L) or [h,w,3] (RGB) arrays of any sizes -> (ctypes array of mocr_image, keep-alive list)."""
+        keep = []
+        descs = (_capi.MocrImage * len(images))()
+        for i, im in enumerate(images):
+            a = np.ascontiguousarray(im, dtype=np.uint8)
+            if a.ndim == 2:
+                ch = 1
+            elif a.ndim == 3 and a.shape[2] == 3:
+                ch = 3
+            else:
+                raise ValueError("each image must be uint8 [h,w] or [h,w,3]")
+            keep.append(a)
+            descs[i].data = a.ctypes.data
+            descs[i].height, descs[i].width = a.shape[0], a.shape[1]
+            descs[i].row_stride = a.shape[1] * ch
+            descs[i].channels = ch
+        return descs, keep
+
+    def recognize_images(self, images) -> Tuple[np.ndarray, np.ndarray]:
+        """Crops of any sizes (list of uint8 [h,w] / [h,w,3] arrays): luminance conversion and the Pillow-exact
+        BILINEAR resize to 224x224 run on the device.  Returns (ids int32 [n,max_len], lengths int32 [n])."""
+        descs, keep = self._image_descs(images)
+        n = len(keep)
+        ids = np.zeros((n, self.spec.max_len), dtype=np.int32)
+        lens = np.zeros(n, dtype=np.int32)
+        self._check(self.lib.mocr_recognize_images(self._h, descs, n, _ptr(ids), _ptr(lens)))
+        return ids, lens
+
+    def preprocess(self, images) -> np.ndarray:
+        """Test hook: the uint8 [n,224,224] planes the encoder sees for these crops."""
+        descs, keep = self._image_descs(images)
+        out = np.zeros((len(keep), self.spec.image_size, self.spec.image_size), dtype=np.uint8)
+        self._check(self.lib.mocr_preprocess(self._h, descs, len(keep), _ptr(out)))
+        return out
+
     def recognize_device(self, d_gray, n: int, d_out_ids, d_out_len) -> None:
         """Asynchronous; all three are device buffers (torch CUDA tensors or raw addresses)."""
         self._check(self.lib.mocr_recognize_device(self._h, _ptr(d_gray), n, _ptr(d_out_ids), _ptr(d_out_len)))

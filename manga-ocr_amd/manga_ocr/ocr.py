@@ -42,14 +42,24 @@ def _resolve_model_dir(name_or_path: str) -> Optional[str]:
 
 
 def to_gray224(img, size: int = 224) -> np.ndarray:
-    """PIL image -> uint8 [224,224]: ``convert('L')`` then the HF image processor's
-    ``resize((224,224), BILINEAR)`` (identity for 224x224 crops).  Equivalent to the
-    reference's convert('L').convert('RGB') + resize because the three channels are equal."""
+    """PIL image -> uint8 [224,224] ON THE HOST: ``convert('L')`` then the HF image processor's
+    ``resize((224,224), BILINEAR)``.  Kept for callers that want the plane itself; the recogniser's own
+    path (:func:`to_pixels`) leaves both steps to the device, which is bit-exact with this."""
     from PIL import Image
     g = img.convert("L")
     if g.size != (size, size):
         g = g.resize((size, size), Image.BILINEAR)
     return np.asarray(g, dtype=np.uint8)
+
+
+def to_pixels(img) -> np.ndarray:
+    """PIL image -> the uint8 array handed to the engine: [h,w,3] for RGB crops (what the reference builds at
+    ``src/ui/main_window.py:9796-9800``), [h,w] for L; any other mode goes through Pillow's own convert('L')
+    first (palettes, alpha, 16-bit ...: rare, and not worth restating).  ``convert('L')`` of RGB and the
+    BILINEAR resize to 224x224 then run on the device (csrc/preprocess.h)."""
+    if img.mode not in ("RGB", "L"):
+        img = img.convert("L")
+    return np.asarray(img, dtype=np.uint8)
 
 
 class _Batcher:
@@ -88,7 +98,7 @@ class _Batcher:
                     self._cv.wait(left)
                 batch, self._q = self._q[:self.max_batch], self._q[self.max_batch:]
             try:
-                ids, lens = self.engine.recognize(np.stack([g for g, _ in batch]))
+                ids, lens = self.engine.recognize_images([g for g, _ in batch])
                 for i, (_, f) in enumerate(batch):
                     f.set_result(ids[i, :lens[i]].copy())
             except BaseException as exc:  # every waiting caller gets the error; the loop lives on
@@ -144,19 +154,19 @@ class MangaOcr:
             img = img_or_path
         else:
             raise ValueError(f"img_or_path must be a path or PIL.Image, instead got: {img_or_path}")
-        ids = self._batcher.submit(to_gray224(img, self.spec.image_size)).result()
+        ids = self._batcher.submit(to_pixels(img)).result()
         return ids_to_text(self.vocab, ids)
 
     # ------------------------------------------------------------------ batch surface (callers that hold many crops)
-    def recognize_ids(self, grays: Sequence[np.ndarray]) -> List[np.ndarray]:
-        ids, lens = self.engine.recognize(np.stack(list(grays)))
+    def recognize_ids(self, crops: Sequence[np.ndarray]) -> List[np.ndarray]:
+        """uint8 crops of any sizes ([h,w] luminance or [h,w,3] RGB) -> token ids (without padding)."""
+        ids, lens = self.engine.recognize_images(list(crops))
         return [ids[i, :lens[i]].copy() for i in range(len(lens))]
 
     def recognize_batch(self, images: Sequence) -> List[str]:
         """All crops of a page (or chapter) at once - what ``_collect_manga_detections``
         (``src/ui/main_window.py:9462-9476``) does one region at a time."""
-        grays = [to_gray224(im, self.spec.image_size) for im in images]
-        return [ids_to_text(self.vocab, r) for r in self.recognize_ids(grays)]
+        return [ids_to_text(self.vocab, r) for r in self.recognize_ids([to_pixels(im) for im in images])]
 
     def close(self) -> None:
         self._batcher.close()

@@ -217,7 +217,11 @@ def test_mangaocr_call_surface_and_thread_batching():
         assert texts == want and all(isinstance(t, str) and t for t in texts)
         assert m.recognize_batch(imgs) == want
         big = Image.fromarray(np.random.RandomState(1).randint(0, 256, (301, 117, 3), dtype=np.uint8), mode="RGB")
-        assert isinstance(m(big), str)                         # non-224 crops go through the PIL-exact resize
+        # non-224 crops: luminance + resize on the device == Pillow's own convert('L').resize(BILINEAR) on the host
+        from manga_ocr.ocr import to_gray224
+        assert m(big) == ids_to_text(m.vocab, m.recognize_ids([to_gray224(big)])[0])
+        rgba = big.convert("RGBA")                             # exotic modes: Pillow's convert('L') first, like the reference
+        assert m(rgba) == m(big)
         with pytest.raises(ValueError):
             m(np.zeros((224, 224, 3), dtype=np.uint8))
     finally:
