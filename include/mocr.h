@@ -48,7 +48,8 @@ enum {
     MOCR_FLAG_SIMPLE_ATTENTION = 1 << 0, /* encoder attention on the VALU kernel even in bf16 mode */
     MOCR_FLAG_NO_GRAPH = 1 << 1,         /* launch decode steps eagerly instead of replaying a HIP graph */
     MOCR_FLAG_NO_EARLY_EXIT = 1 << 2,    /* always run max_len-1 decode steps */
-    MOCR_FLAG_CLASSIC_ATTENTION = 1 << 3 /* bf16: projected K/V caches instead of the latent (absorbed) decode attention */
+    MOCR_FLAG_CLASSIC_ATTENTION = 1 << 3, /* bf16: projected K/V caches instead of the latent (absorbed) decode attention */
+    MOCR_FLAG_NO_FUSED_ARGMAX = 1 << 4    /* always write the logits and take the argmax in the token kernel */
 };
 
 typedef struct mocr_engine mocr_engine;

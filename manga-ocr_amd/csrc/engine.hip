@@ -91,6 +91,7 @@ struct LaneCtx {
     void *Xn = nullptr, *QKV = nullptr, *CTX = nullptr, *Hb = nullptr, *ENC = nullptr, *CKV = nullptr;
     void *kcache = nullptr, *vcache = nullptr;     // [dec_layers][Bp][H][max_len][64]
     float* slabs = nullptr; long long slab_cap = 0; // floats
+    float* cand_val = nullptr; int* cand_idx = nullptr;   // [Bp][vocab/64] per-tile argmax candidates of the LM head
     float *x_f32 = nullptr, *a_f32 = nullptr, *c_f32 = nullptr;
     void *x_t = nullptr, *a_t = nullptr, *c_t = nullptr, *ctx_t = nullptr, *h_t = nullptr, *z_t = nullptr;
     int *ids = nullptr, *step = nullptr, *finished = nullptr, *len = nullptr, *n_unf = nullptr;
@@ -250,6 +251,7 @@ void launch_gemm_epi(mocr_engine* e, const GemmParams& p, int epi, int split, in
         case EPI_BIAS_RESID: launch_gemm_t<T, BM, BN, EPI_BIAS_RESID>(e, p, split, ybatch); break;
         case EPI_PATCH: launch_gemm_t<T, BM, BN, EPI_PATCH>(e, p, split, ybatch); break;
         case EPI_BIAS_F32: launch_gemm_t<T, BM, BN, EPI_BIAS_F32>(e, p, split, ybatch); break;
+        case EPI_ARGMAX: launch_gemm_t<T, BM, BN, EPI_ARGMAX>(e, p, split, ybatch); break;
         default: throw ArgError{"unknown GEMM epilogue", MOCR_ERR_ARG};
     }
 }
@@ -311,13 +313,13 @@ struct HeadBatch { int heads = 1; long long a_yoff = 0, w_yoff = 0, o_yoff = 0, 
 template <typename T>
 void gemm(mocr_engine* e, const char* name, const void* A, int lda, const void* W, const float* bias, void* out, int ldo,
           const float* resid, int M, int N, int K, int epi, int tile, int split, long long slab_stride = 0,
-          const float* pos = nullptr, int patches = 0, const HeadBatch* hb = nullptr, int group_n = 0) {
+          const float* pos = nullptr, int patches = 0, const HeadBatch* hb = nullptr, int group_n = 0, int* cand_idx = nullptr) {
     const int kt = 128 / (int)sizeof(T);
     if (N % (tile == 1024 ? 256 : tile >= 256 ? 128 : tile) || K % (kt * split) || (split > 1 && epi != EPI_SLAB) ||
         (tile >= 256 && (sizeof(T) != 2 || split != 1)))
         throw ArgError{std::string("gemm shape not tileable: ") + name, MOCR_ERR_ARG};
     GemmParams p{};
-    p.A = A; p.W = W; p.bias = bias; p.out = out; p.resid = resid; p.pos = pos;
+    p.A = A; p.W = W; p.bias = bias; p.out = out; p.resid = resid; p.pos = pos; p.cand_idx = cand_idx;
     p.M = M; p.N = N; p.lda = lda; p.ldw = K; p.ldo = ldo;
     int ybatch = 1;
     if (hb) {
@@ -479,13 +481,13 @@ static DecState make_state(mocr_engine* e, int max_len, const int* forced, int f
 }
 
 template <typename T, bool FIRST>
-void dec_token(mocr_engine* e, const DecState& st, int nslab, int n) {
+void dec_token(mocr_engine* e, const DecState& st, int nslab, int n, int ncand = 0) {
     auto& w = e->w;
     ProfScope ps(e, FIRST ? "dec_token_first" : "dec_token", 0, FIRST ? 0.0 : (double)n * e->V * 4 * nslab);
     hipLaunchKernelGGL((dec_token_kernel<T, 768, FIRST>), dim3(n), dim3(256), 0, e->stream, e->slabs, nslab,
                        (long long)e->Bp * e->V, w.bv, e->V, st, w.word, w.type0, w.posd, w.embg, w.embb, e->x_f32,
                        reinterpret_cast<T*>(e->x_t), e->cfg.ln_eps, e->latent ? reinterpret_cast<T*>(e->xcache) : nullptr,
-                       (long long)e->cfg.max_len * e->D);
+                       (long long)e->cfg.max_len * e->D, ncand ? e->cand_val : nullptr, ncand ? e->cand_idx : nullptr, ncand);
     HIPCHECK(hipGetLastError());
 }
 
@@ -616,8 +618,19 @@ void decode_step(mocr_engine* e, const DecState& st, int n, int t) {
     }
     int ns = dec_gemm<T>(e, "gemm_dec_proj", e->x_t, D, w.wt, D, D, n);
     dec_add_ln<T>(e, ns, D, w.bt, nullptr, w.lntg, w.lntb, nullptr, e->z_t, n, true);
-    ns = dec_gemm<T>(e, "gemm_dec_vocab", e->z_t, D, w.wv, e->V, D, n);
-    dec_token<T, false>(e, st, ns, n);
+    // LM head.  When the GEMM is not split over K and nobody asked for the logits, its epilogue reduces every N-tile
+    // to (max, column) and the token kernel picks among V/tile candidates: the [n, V] fp32 logits (100 MB at 4096
+    // rows) are neither written nor read.  acc + bias is the same fp32 value either way, so the argmax is identical.
+    const int vt = dec_tile(n);
+    if (!st.logits_out && !(e->cfg.flags & MOCR_FLAG_NO_FUSED_ARGMAX) && (vt == 64 || vt == 128) &&
+        pick_split(e->V, D, 128 / (int)sizeof(T), n, e->slab_cap / e->Bp) == 1) {
+        gemm<T>(e, "gemm_dec_vocab", e->z_t, D, w.wv, w.bv, e->cand_val, e->V, nullptr, n, e->V, D, EPI_ARGMAX, vt, 1, 0, nullptr, 0,
+                nullptr, 0, e->cand_idx);
+        dec_token<T, false>(e, st, 1, n, e->V / vt);
+    } else {
+        ns = dec_gemm<T>(e, "gemm_dec_vocab", e->z_t, D, w.wv, e->V, D, n);
+        dec_token<T, false>(e, st, ns, n);
+    }
 }
 
 template <typename T>
@@ -638,12 +651,14 @@ template <typename T> void init_kernel_attrs() {
     set_max_lds(gemm_kernel<T, 128, 128, EPI_BIAS_RESID>, l128);
     set_max_lds(gemm_kernel<T, 128, 128, EPI_PATCH>, l128);
     set_max_lds(gemm_kernel<T, 128, 128, EPI_BIAS_F32>, l128);
+    set_max_lds(gemm_kernel<T, 128, 128, EPI_ARGMAX>, l128);
     set_max_lds(gemm_kernel<T, 64, 64, EPI_SLAB, 2>, l64);
     set_max_lds(gemm_kernel<T, 64, 64, EPI_BIAS, 2>, l64);
     set_max_lds(gemm_kernel<T, 64, 64, EPI_BIAS_GELU, 2>, l64);
     set_max_lds(gemm_kernel<T, 64, 64, EPI_BIAS_RESID, 2>, l64);
     set_max_lds(gemm_kernel<T, 64, 64, EPI_PATCH, 2>, l64);
     set_max_lds(gemm_kernel<T, 64, 64, EPI_BIAS_F32, 2>, l64);
+    set_max_lds(gemm_kernel<T, 64, 64, EPI_ARGMAX, 2>, l64);
     set_max_lds(enc_attn_simple_kernel<T>, (200 * 65 + 200 * 64 + 4 * 64 + 4 * 256) * 4);
     set_max_lds(enc_attn_mfma_kernel, ENC_SP * 128 + 64 * ENC_VT_LD * 2);
     constexpr int l256 = 3 * (256 + 128) * 128;
@@ -1031,6 +1046,7 @@ void allocate_lane(mocr_engine* e, int lane_id) {
     }
     e->slab_cap = (long long)Bp * 12288;
     e->slabs = e->dalloc<float>((size_t)e->slab_cap);
+    e->cand_val = e->dalloc<float>((size_t)Bp * (e->V / 64)); e->cand_idx = e->dalloc<int>((size_t)Bp * (e->V / 64));
     e->x_f32 = e->dalloc<float>(Bp * D); e->a_f32 = e->dalloc<float>(Bp * D); e->c_f32 = e->dalloc<float>(Bp * D);
     e->x_t = e->dalloc<char>(Bp * D * esz); e->a_t = e->dalloc<char>(Bp * D * esz); e->c_t = e->dalloc<char>(Bp * D * esz);
     e->ctx_t = e->dalloc<char>(Bp * D * esz); e->z_t = e->dalloc<char>(Bp * D * esz);

@@ -123,7 +123,9 @@ __global__ __launch_bounds__(256) void dec_token_kernel(const float* __restrict_
                                                         const float* __restrict__ pos, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float* __restrict__ x_f32,
                                                         T* __restrict__ x_t, float eps, T* __restrict__ cache = nullptr,
-                                                        long long cache_batch_stride = 0) {
+                                                        long long cache_batch_stride = 0,
+                                                        const float* __restrict__ cand_val = nullptr,
+                                                        const int* __restrict__ cand_idx = nullptr, int ncand = 0) {
     __shared__ float s_val[4];
     __shared__ int s_idx[4];
     __shared__ float s_red[4];
@@ -140,6 +142,14 @@ __global__ __launch_bounds__(256) void dec_token_kernel(const float* __restrict_
         const int t = st.step[b];
         float best = -INFINITY;
         int bi = 0x7fffffff;
+        if (cand_val) {
+            // the LM-head GEMM already reduced every 64/128-column tile (EPI_ARGMAX): ncand candidates per row
+            for (int c = tid; c < ncand; c += 256) {
+                const float cv = cand_val[(size_t)b * ncand + c];
+                const int ci = cand_idx[(size_t)b * ncand + c];
+                if (cv > best || (cv == best && ci < bi)) { best = cv; bi = ci; }
+            }
+        } else {
         constexpr int NC = 6;                            // vocab = NC * 1024 columns (6144)
         float4 a[NC];
 #pragma unroll
@@ -161,6 +171,7 @@ __global__ __launch_bounds__(256) void dec_token_kernel(const float* __restrict_
             if (a[j].y > best) { best = a[j].y; bi = c + 1; }
             if (a[j].z > best) { best = a[j].z; bi = c + 2; }
             if (a[j].w > best) { best = a[j].w; bi = c + 3; }
+        }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {

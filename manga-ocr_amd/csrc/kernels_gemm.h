@@ -32,7 +32,9 @@ enum GemmEpilogue {
     EPI_BIAS_GELU = 2,   // out T   = gelu(acc + bias)
     EPI_BIAS_RESID = 3,  // out f32 = (acc + bias) + resid        (out may alias resid)
     EPI_PATCH = 4,       // patch-embed: out f32[b*197+1+p] = (acc + bias) + pos[1+p]
-    EPI_BIAS_F32 = 5     // out f32 = acc + bias
+    EPI_BIAS_F32 = 5,    // out f32 = acc + bias
+    EPI_ARGMAX = 6       // LM head: per (row, N-tile) the fp32 max of acc + bias and its column (lowest column wins ties):
+                         //   out f32 [M][ntn] values, cand_idx int [M][ntn] columns - the logits never go to memory
 };
 
 struct GemmParams {
@@ -42,6 +44,7 @@ struct GemmParams {
     void* out;
     const float* resid;
     const float* pos;      // EPI_PATCH: [tokens][N] position embeddings
+    int* cand_idx;         // EPI_ARGMAX: [M][ntn] winning columns
     int M, N;              // logical output size (rows >= M are computed but not stored)
     int lda, ldw, ldo;     // leading dimensions in elements
     int k_per_split;       // elements of K handled by one blockIdx.z
@@ -122,6 +125,44 @@ __device__ __forceinline__ void gemm_epilogue(const float* sC, const GemmParams&
             float* o = reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n;
             *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
         }
+    }
+}
+
+// EPI_ARGMAX: every output row of the tile is reduced to (max of acc + bias, its column; the lowest column wins ties).
+// NT / BM threads share a row (adjacent lanes); a thread scans its BN / (NT/BM) physical columns of the LDS tile 4 at a
+// time, starting at a row-dependent rotation so that the 16 lanes of a ds_read_b128 group hit 16 different 16-byte
+// slots.  SWZ: the tile's 16-column groups are XORed with (row>>2)&3 (see gemm_epilogue): physical -> logical column.
+template <int BM, int BN, int NT, bool SWZ>
+__device__ __forceinline__ void gemm_epilogue_argmax(const float* sC, const GemmParams& p, int m0, int n0, int tid) {
+    constexpr int TPRW = NT / BM, CPP = BN / TPRW;
+    static_assert(TPRW == 2 || TPRW == 4, "two or four threads per row");
+    const int row = tid / TPRW, part = tid % TPRW;
+    const int m = m0 + row;
+    const int sw = SWZ ? (((row >> 2) & 3) << 4) : 0;
+    const int rot = 4 * (row % (CPP / 4));
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int q = 0; q < CPP / 4; ++q) {
+        const int pc = part * CPP + ((rot + 4 * q) % CPP);          // physical column of this float4
+        const float4 cv = *reinterpret_cast<const float4*>(&sC[row * BN + pc]);
+        const int n = n0 + (pc ^ sw);                                // logical (global) column of cv.x
+        const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+        const float v[4] = {cv.x + bv.x, cv.y + bv.y, cv.z + bv.z, cv.w + bv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (v[e] > best || (v[e] == best && n + e < bi)) { best = v[e]; bi = n + e; }
+    }
+#pragma unroll
+    for (int o = TPRW / 2; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (part == 0 && m < p.M) {
+        const size_t c = (size_t)m * p.ntn + n0 / BN;
+        reinterpret_cast<float*>(p.out)[c] = best;
+        p.cand_idx[c] = bi;
     }
 }
 
@@ -326,7 +367,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     }
     __syncthreads();
 
-    if constexpr (EPI == EPI_BIAS) {
+    if constexpr (EPI == EPI_ARGMAX) {
+        gemm_epilogue_argmax<BM, BN, 256, SWZ>(sC, p, m0, n0, tid);
+    } else if constexpr (EPI == EPI_BIAS) {
         GemmParams q = p;
         q.out = reinterpret_cast<T*>(p.out) + (size_t)blockIdx.y * p.o_yoff;
         q.bias = p.bias + (size_t)blockIdx.y * p.b_yoff;

@@ -226,3 +226,18 @@ def test_mangaocr_call_surface_and_thread_batching():
             m(np.zeros((224, 224, 3), dtype=np.uint8))
     finally:
         m.close()
+
+
+def test_fused_lm_head_argmax_equals_logits_argmax():
+    """Fat batches (no split-K) let the LM-head GEMM reduce each N-tile to (max, column) in its epilogue; the ids must
+    equal those of the path that writes the logits and takes the argmax in the token kernel (flag 16), in both modes."""
+    gray = crops(77, 160)
+    for dtype in ("bf16", "fp32"):
+        ml = 300 if dtype == "bf16" else 40
+        a = engine(dtype, max_batch=160)
+        b = engine(dtype, max_batch=160, flags=16)
+        ids_a, len_a = a.recognize_gray(gray, max_len=ml)
+        ids_b, len_b = b.recognize_gray(gray, max_len=ml)
+        np.testing.assert_array_equal(ids_a, ids_b)
+        np.testing.assert_array_equal(len_a, len_b)
+    report("fused LM-head argmax == logits argmax (160 rows, bf16 300 tokens / fp32 40 tokens)")
