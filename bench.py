@@ -72,7 +72,7 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--lanes", type=int, default=2, help="internal batches the engine keeps in flight (streams + workspaces)")
     ap.add_argument("--max-batch", type=int, default=4096, help="rows of one internal engine batch: submitted steps are merged up to this")
-    ap.add_argument("--cpu-sample", type=int, default=16)
+    ap.add_argument("--cpu-sample", type=int, default=96, help="crops the CPU baseline (oracle) decodes: ~12 s on 16 host threads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
