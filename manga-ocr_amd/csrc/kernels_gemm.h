@@ -775,3 +775,4 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void gemm_wide_kernel(Ge
     }
 #undef MOCR_LOAD_RESID
 }
+
