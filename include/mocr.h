@@ -49,7 +49,8 @@ enum {
     MOCR_FLAG_NO_GRAPH = 1 << 1,         /* launch decode steps eagerly instead of replaying a HIP graph */
     MOCR_FLAG_NO_EARLY_EXIT = 1 << 2,    /* always run max_len-1 decode steps */
     MOCR_FLAG_CLASSIC_ATTENTION = 1 << 3, /* bf16: projected K/V caches instead of the latent (absorbed) decode attention */
-    MOCR_FLAG_NO_FUSED_ARGMAX = 1 << 4    /* always write the logits and take the argmax in the token kernel */
+    MOCR_FLAG_NO_FUSED_ARGMAX = 1 << 4,   /* always write the logits and take the argmax in the token kernel */
+    MOCR_FLAG_NO_FUSED_QQT = 1 << 5       /* latent attention: query and absorbed query as two GEMM launches even for fat batches */
 };
 
 typedef struct mocr_engine mocr_engine;
@@ -155,6 +156,11 @@ int mocr_op_enc_attention(mocr_engine* e, const void* d_qkv, void* d_ctx, int32_
  * sequences, context length len for every row; d_out [n,16,768] = softmax(qt . x^T) x per head. */
 int mocr_op_latent_attention(mocr_engine* e, const void* d_qt, const void* d_x, void* d_out, int32_t n, int32_t len,
                              int64_t x_batch_stride);
+
+/* Fused query path of the latent attention (bf16 engines): d_x [rows_pad,768] bf16 (rows_pad = n rounded up to 128),
+ * d_wq [768,768] bf16, d_bq [768] f32, d_wkT [768,768] bf16 (row n, column 64h+k = Wk_h[k][n]/8), d_qt [rows_pad,16,768] bf16:
+ * d_qt[m][h] = bf16(x[m] . Wq_h^T + bq_h) . wkT_h   for the 12 heads. */
+int mocr_op_qqt(mocr_engine* e, const void* d_x, const void* d_wq, const float* d_bq, const void* d_wkT, void* d_qt, int32_t n);
 
 /* ---- per-kernel timing (HIP events on the engine's stream) -------------------------------- */
 typedef struct mocr_kernel_stat {

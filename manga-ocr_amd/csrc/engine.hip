@@ -30,6 +30,7 @@
 #include "kernels_gemm.h"
 #include "kernels_latent.h"
 #include "preprocess.h"
+#include "kernels_qqt.h"
 #include "kernels_misc.h"
 
 namespace {
@@ -168,6 +169,9 @@ struct mocr_engine : LaneCtx {
         void* p = nullptr;
         HIPCHECK(hipMalloc(&p, std::max<size_t>(count * sizeof(X_), 256)));
         HIPCHECK(hipMemset(p, 0, std::max<size_t>(count * sizeof(X_), 256)));
+        // the fill runs on the null stream, which the lanes' non-blocking streams do not wait for: a buffer
+        // allocated lazily (test hooks) could otherwise be zeroed AFTER its first asynchronous upload
+        HIPCHECK(hipDeviceSynchronize());
         allocs.push_back(p);
         return reinterpret_cast<X_*>(p);
     }
@@ -285,13 +289,8 @@ void launch_gemm_wide_t(mocr_engine* e, const GemmParams& p0) {
     p.ntm = ntm;
     // persistent: one (256x256) or two (256x128) blocks per CU, a multiple of 8 so that every XCD gets the same count
     const int ntiles = ntm * p.ntn;
-    // Default: one tile per block (grid = tiles, rounded up to 8: an empty block returns at once).  With
-    // MOCR_GEMM_PERSIST=1 the grid is one (256x256) or two (256x128) blocks per CU and each block walks its tiles:
-    // measured +2 % / -12 % at M = 806,912 (r01) - these GEMMs are bound by the L2's bandwidth, writes included,
-    // not by the store drain at block end - so it stays an experiment.
-    static const int persist = env_int("MOCR_GEMM_PERSIST", 0);
-    const int full = (ntiles + 7) / 8 * 8;
-    const int grid = persist ? std::min(e->num_cus * (WN == 2 ? 2 : 1), full) : full;
+    // one tile per block; the grid is rounded up to 8 so that every XCD gets the same count (an empty block returns at once)
+    const int grid = (ntiles + 7) / 8 * 8;
     hipLaunchKernelGGL((gemm_wide_kernel<EPI, WN>), dim3(grid), dim3(128 * WN), 3 * (256 + 64 * WN) * 64, e->stream, p);
     HIPCHECK(hipGetLastError());
 }
@@ -563,6 +562,24 @@ void latent_block(mocr_engine* e, bool self, int layer, int n, int t, const void
                   const void* wkT, const void* wv, const float* bv) {
     using T = bf16_t;
     const int D = e->D;
+    // fat batches: q and Qt in one launch (kernels_qqt.h); MOCR_DEC_QQT_ROWS = rows from which it is used (0 = never)
+    static const int qqt_rows = env_int("MOCR_DEC_QQT_ROWS", 1024);
+    static const int qqt_only = env_int("MOCR_QQT_ONLY", 0);   // debugging: 1 = self only, 2 = cross only
+    if (qqt_rows > 0 && n >= qqt_rows && D == 768 && e->H == 12 && !(e->cfg.flags & MOCR_FLAG_NO_FUSED_QQT) &&
+        (qqt_only == 0 || (qqt_only == 1) == self)) {
+        QqtParams q{};
+        q.x = reinterpret_cast<const bf16_t*>(xin); q.wq = reinterpret_cast<const bf16_t*>(wq); q.bq = bq;
+        q.wkT = reinterpret_cast<const bf16_t*>(wkT); q.qt = reinterpret_cast<bf16_t*>(e->qt);
+        {
+            ProfScope ps(e, "dec_qqt", 4.0 * n * D * D, (double)n * D * 2 + 2.0 * D * D * 2 + (double)n * e->H * D * 2);
+            hipLaunchKernelGGL(dec_qqt_kernel, dim3((n + 127) / 128, e->H), dim3(256), QQT_LDS, e->stream, q);
+            HIPCHECK(hipGetLastError());
+        }
+        latent_attn(e, self, layer, n, self ? t + 1 : e->S);
+        HeadBatch hc2; hc2.heads = e->H; hc2.a_yoff = D; hc2.w_yoff = (long long)64 * D; hc2.o_yoff = 64; hc2.b_yoff = 64; hc2.ldw = D;
+        gemm<T>(e, "gemm_dec_ctx", e->et, 16 * D, wv, bv, e->ctx_t, D, nullptr, n, 64, D, EPI_BIAS, 64, 1, 0, nullptr, 0, &hc2);
+        return;
+    }
     static const int qtile = env_int("MOCR_DEC_QTILE", 64), qttile_env = env_int("MOCR_DEC_QTTILE", 0);
     const int qttile = qttile_env ? qttile_env : (n >= 1024 ? 128 : 64);      // Qt is output-write bound: fewer, fatter blocks
     gemm<T>(e, "gemm_dec_q", xin, D, wq, bq, e->q_t, D, nullptr, n, D, D, EPI_BIAS, qtile, 1);
@@ -661,6 +678,7 @@ template <typename T> void init_kernel_attrs() {
     set_max_lds(gemm_kernel<T, 64, 64, EPI_ARGMAX, 2>, l64);
     set_max_lds(enc_attn_simple_kernel<T>, (200 * 65 + 200 * 64 + 4 * 64 + 4 * 256) * 4);
     set_max_lds(enc_attn_mfma_kernel, ENC_SP * 128 + 64 * ENC_VT_LD * 2);
+    set_max_lds(dec_qqt_kernel, QQT_LDS);
     constexpr int l256 = 3 * (256 + 128) * 128;
     set_max_lds(gemm_wide_kernel<EPI_BIAS, 2>, 3 * (256 + 128) * 64);
     set_max_lds(gemm_wide_kernel<EPI_BIAS_GELU, 2>, 3 * (256 + 128) * 64);
@@ -1477,6 +1495,23 @@ int mocr_op_latent_attention(mocr_engine* e, const void* d_qt, const void* d_x, 
             }
             fprintf(stderr, "[lat stamps, cycles] wait+issue %llu  S %llu  exchange %llu  softmax %llu  PX %llu  other %llu\n", h[0], h[1], h[2], h[3], h[4], h[5]);
         }
+    });
+}
+
+int mocr_op_qqt(mocr_engine* e, const void* d_x, const void* d_wq, const float* d_bq, const void* d_wkT, void* d_qt, int32_t n) {
+    return guarded(e, [&] {
+        std::lock_guard<std::mutex> lk(e->mu);
+        HIPCHECK(hipSetDevice(e->cfg.device));
+        drive(e);
+        e->bind(0);
+        if (e->cfg.dtype != MOCR_BF16 || !d_x || !d_wq || !d_bq || !d_wkT || !d_qt || n < 1) throw ArgError{"bad argument", MOCR_ERR_ARG};
+        QqtParams q{};
+        q.x = reinterpret_cast<const bf16_t*>(d_x); q.wq = reinterpret_cast<const bf16_t*>(d_wq); q.bq = d_bq;
+        q.wkT = reinterpret_cast<const bf16_t*>(d_wkT); q.qt = reinterpret_cast<bf16_t*>(d_qt);
+        ProfScope ps(e, "op_qqt", 4.0 * n * 768 * 768, 0);
+        hipLaunchKernelGGL(dec_qqt_kernel, dim3((n + 127) / 128, 12), dim3(256), QQT_LDS, e->stream, q);
+        HIPCHECK(hipGetLastError());
+        HIPCHECK(hipStreamSynchronize(e->stream));
     });
 }
 

@@ -531,12 +531,11 @@ __global__ __launch_bounds__(256, 1) void gemm256_kernel(GemmParams p) {
 // WN = waves along N: 2 -> 256 x 128 tile, 256 threads, two blocks per CU;
 //                     4 -> 256 x 256 tile, 512 threads (8 waves = 2 per SIMD), one block per CU: 2/3 of the L2 -> LDS
 //                          bytes per FLOP of the 256 x 128 tile (the L2 itself, ~16 TB/s, is what bounds these GEMMs)
-// PERSISTENT: the grid is one (WN = 4) or two (WN = 2) blocks per CU and every block walks its share of the
-// tiles.  A block that ends cannot hand its CU to the next block before its output stores have been acknowledged,
-// which exposed the whole store drain once per tile (r01: 0.73 of 3.3 ms on QKV, = the 3.7 GB of output at HBM
-// speed).  Here the stores of tile i drain while tile i+1 is multiplied: the first two K-tiles of tile i+1 are
-// requested BEFORE the epilogue's stores (so they are older in the in-order vmcnt queue), and the waits count the
-// epilogue's instructions (a compile-time constant) among the younger ones.  The XCD-aware tile map: XCD x (= blockIdx & 7) owns a contiguous chunk of the tile list.
+// One tile per block; XCD x (= blockIdx & 7) owns a contiguous chunk of the tile list.  (A persistent variant that
+// requested the next tile's first K-tiles before the epilogue's stores, so that the stores drained behind the next
+// tile's MFMAs, gained 2 % on the 256 x 256 tile and lost 12 % on 256 x 128 - these GEMMs are bound by the L2's
+// bandwidth, writes included, not by the store drain at block end - and its waits had to count stores as younger
+// instructions than the in-flight LDS-DMA, which is not safe on this part (see kernels_qqt.h).  Removed.)
 template <int EPI, int WN>
 __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void gemm_wide_kernel(GemmParams p) {
     using T = bf16_t;
@@ -552,7 +551,6 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void gemm_wide_kernel(Ge
     // this block's tiles: chunk of XCD (blockIdx & 7), positions (blockIdx >> 3) + k * (gridDim >> 3)
     const int ntiles = p.ntm * p.ntn;
     int tile, tile_end;
-    const int tstride = gridDim.x >> 3;
     {
         const int xcd = blockIdx.x & 7, q = ntiles >> 3, r = ntiles & 7;
         const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
@@ -590,14 +588,11 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void gemm_wide_kernel(Ge
     const int frag_off = l15 * 64 + ((g4 ^ (((l15 >> 3) & 1) << 1)) << 4);
     const int offA = (wm * 128) * 64 + frag_off, offB = A_BYTES + (wn * 64) * 64 + frag_off;
 
-    // VMEM instructions of one epilogue (after the bias loads): 16 stores, or 32 residual loads + 32 stores
-    constexpr int EOPS = EPI == EPI_BIAS_RESID ? 64 : 16;
-    bool first = true;
     set_tile(tile);
     stage(a_base, w_base, 0, 0);
     if (nt > 1) stage(a_base, w_base, 1, 1);
 
-    while (true) {
+    {
         f32x4 acc[4][8];      // [n-tile j][m-tile i]: lane holds C[m = 16i + l15][n = 16j + 4*g4 + r]
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -608,14 +603,8 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void gemm_wide_kernel(Ge
 
         for (int t = 0; t < nt; ++t) {
             const int slot = t % NST;
-            // K-tile t has landed (this wave's pieces).  Younger than its request: the next K-tile's DMA (if any) and,
-            // for the first two K-tiles of a follow-on tile, the previous tile's epilogue (EOPS instructions, issued
-            // after this tile's first two requests).  Four immediates; no jump table on the K-loop's critical path.
-            {
-                const bool nxt = t + 1 < nt, epi = t < 2 && !first;
-                if (!epi) { if (nxt) wait_vmcnt<LPT>(); else wait_vmcnt<0>(); }
-                else { if (nxt) wait_vmcnt<(LPT + EOPS < 63 ? LPT + EOPS : 63)>(); else wait_vmcnt<(EOPS < 63 ? EOPS : 63)>(); }
-            }
+            // K-tile t has landed (this wave's pieces); the next K-tile's DMA (if any) stays in flight
+            if (t + 1 < nt) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();                                            // ... everyone's; and slot (t+2)%3 is free
             asm volatile("" ::: "memory");
             if (t + 2 < nt && !(p.ablate & 2)) {
@@ -656,8 +645,7 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void gemm_wide_kernel(Ge
             }
         }
 
-        // bias of this lane's 16 columns: loaded (and waited for) before the next tile's DMA is in flight - a
-        // compiler wait for it further down would be vmcnt(0) and drain that DMA
+        // bias of this lane's 16 columns
         const int em0 = m0, en0 = n0;
         const int nb = en0 + wn * 64 + 4 * g4;
         float bias[4][4];
@@ -669,30 +657,16 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void gemm_wide_kernel(Ge
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(bias[j][r]));
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-
-        // ---- next tile: its first K-tiles are requested before this tile's stores
-        const int next = tile + tstride;
-        const bool more = next < tile_end;
-        if (more) {
-            __builtin_amdgcn_s_barrier();             // every wave is past its last fragment reads: the ring is free
-            asm volatile("" ::: "memory");
-            set_tile(next);
-            stage(a_base, w_base, 0, 0);
-            if (nt > 1) stage(a_base, w_base, 1, 1);
-        }
-
-        // (the VMEM instruction order is the bookkeeping: nothing may move across this point)
+            for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(bias[j][r]));      // landed before the asm loads below are counted
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
 
         // ---- fused epilogue from the registers
         if (!(p.ablate & 4)) {
-            // residual rows: inline-asm loads, software-pipelined one row group ahead of the stores.  vmcnt retires in
-            // order, so a load issued AFTER the previous group's stores could only be waited for together with those
-            // stores' acknowledgements; requested before them, its wait lets the stores (and the next loads) fly.
+            // residual rows: inline-asm loads, software-pipelined one row group ahead of the stores (no LDS-DMA is in
+            // flight any more: only ordinary loads and stores, which retire in issue order - the same assumption the
+            // compiler's own waits make).  A load issued AFTER the previous group's stores could only be waited for
+            // together with those stores' acknowledgements; requested before them, its wait lets the stores fly.
             // Rows >= M (guard) read row M-1 instead and are not stored.
             f32x4 rv[2][4];
 #define MOCR_LOAD_RESID(buf, i_)                                                                                   \
@@ -762,16 +736,7 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void gemm_wide_kernel(Ge
                     }
                 }
             }
-            // predicated stores may be skipped altogether (a wave whose rows are all >= M): EOPS is then too high,
-            // which is only safe once everything older has drained
-            if (guard) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        if (p.ablate & 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // diagnostics: no epilogue was issued
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        if (!more) break;
-        tile = next;
-        first = false;
     }
 #undef MOCR_LOAD_RESID
 }

@@ -123,11 +123,15 @@ __device__ __forceinline__ void lds_read3_b128(uint4* o, unsigned a0, unsigned a
 // Persistent: block i handles sequences i, i + gridDim.x, ...; the tile stream (and the DMA ring)
 // runs across sequence boundaries, so only the very first tile of a block waits for HBM.
 //
-// vmcnt bookkeeping.  CDNA counts loads, stores and LDS-DMA together, in issue order, so "X has
-// landed" is s_waitcnt vmcnt(number of VMEM instructions this wave issued after X).  The wave keeps
-// that number at run time: `issued` counts its VMEM instructions (12 global_load_lds per tile, 6
-// inline-asm loads per Qt prefetch, 5 (waves 0, 1) or 4 (waves 2, 3) global stores per finished row - the
-// row is staged through LDS so that the store count is wave-uniform), and every ring slot remembers the count at
+// vmcnt bookkeeping.  LOADS (LDS-DMA and ordinary global loads) come back in issue order, so "load X has
+// landed" is s_waitcnt vmcnt(number of LOADS this wave issued after X).  STORES are deliberately NOT counted as
+// younger instructions: measured on this part (kernels_qqt.h), a vmcnt(N) that lets N younger stores fly does not
+// prove that an older LDS-DMA has landed - the stores' acknowledgements can overtake it.  An outstanding store
+// therefore only ever makes a wait longer, never shorter than it must be; and to keep it from making waits
+// longer in practice, a finished row's stores are issued right AFTER the next row's first tile wait (the row is
+// read back from its LDS staging into registers first), so they have a whole tile period before the next wait.
+// The wave keeps the load count at run time: `issued` (up to 12 global_load_lds per tile, 6 inline-asm loads per
+// Qt prefetch), and every ring slot remembers the count at
 // which its tile was requested.  The Qt loads are inline asm on purpose: an ordinary global load
 // beside LDS-DMA makes hipcc put s_waitcnt vmcnt(0) in front of its first use, which would drain the
 // ring once per tile (cdna_hip_programming.md §5, "Three .s-level traps" (b)).  Because the compiler
@@ -256,7 +260,7 @@ __global__ __launch_bounds__(256, 1) void latent_attn_kernel(LatentParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing else in flight yet: landed before the loop
 #pragma unroll
     for (int s = 0; s < 6; ++s) asm volatile("" : "+v"(qf[s]));
-    int issued = 0;                      // VMEM instructions issued by this wave since then
+    int issued = 0;                      // LOADS (DMA, Qt prefetch) issued by this wave since then; stores are not counted
     int mk0 = 0, mk1 = 0, mk2 = 0;       // `issued` right after the tile of ring slot 0/1/2 was requested
     // issue side of the ring: next (sequence, tile) to request and the slot it goes to
     int ir = cr, it = 0, islot = 0;
@@ -286,6 +290,19 @@ __global__ __launch_bounds__(256, 1) void latent_attn_kernel(LatentParams p) {
     ISSUE_NEXT();
     ISSUE_NEXT();
     int slot = 0;
+    // the previous row's output, read back from its staging image, waiting to be stored (see the header)
+    uint4 pend[5];
+    char* pend_ob = nullptr;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) pend[k] = make_uint4(0, 0, 0, 0);
+#define STORE_PENDING()                                                                                          \
+    do {                                                                                                          \
+        if (pend_ob) {                                                                                            \
+            _Pragma("unroll") for (int k = 0; k < 5; ++k)                                                         \
+                if (k < 4 || wave < 2) *reinterpret_cast<uint4*>(pend_ob + (tid + 256 * k) * 16) = pend[k];       \
+            pend_ob = nullptr;                                                                                    \
+        }                                                                                                         \
+    } while (0)
 
     while (cr < P_rows) {
         // Qt of the next row (L2-resident, 6 loads per lane): requested now, consumed at the row's end
@@ -310,6 +327,11 @@ __global__ __launch_bounds__(256, 1) void latent_attn_kernel(LatentParams p) {
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             ISSUE_NEXT();                         // refills the slot every wave has finished reading
+            if (t == 0) {                         // the previous row's stores: a whole tile period until the next wait
+                __builtin_amdgcn_sched_barrier(0);
+                STORE_PENDING();
+                __builtin_amdgcn_sched_barrier(0);
+            }
             const char* xt = smem + slot * LAT_TILE_BYTES;
             slot = slot + 1 == LAT_NST ? 0 : slot + 1;
             STAMP(0)   // wait + barrier + DMA issue
@@ -457,22 +479,18 @@ __global__ __launch_bounds__(256, 1) void latent_attn_kernel(LatentParams p) {
         asm volatile("" ::: "memory");
         {
             // 1152 chunks of 16 B = 12 heads x 1536 B, contiguous in the output: thread tid moves chunks
-            // tid + 256k, k = 0..3, and chunk tid + 1024 from waves 0 and 1 only (wave-uniform store count)
-            char* ob = reinterpret_cast<char*>(P_out + (size_t)cr * 16 * LAT_D);
-            uint4 v[5];
+            // tid + 256k, k = 0..3, and chunk tid + 1024 (waves 0 and 1 only).  Read back now (the slot is refilled
+            // at the next tile's top), stored after the next row's first tile wait.
             const unsigned sa = lds_addr(stg);
-            lds_read3_b128(v, sa + out_off[0], sa + out_off[1], sa + out_off[2]);
-            lds_read2_b128(v + 3, sa + out_off[3], sa + out_off[4]);
+            lds_read3_b128(pend, sa + out_off[0], sa + out_off[1], sa + out_off[2]);
+            lds_read2_b128(pend + 3, sa + out_off[3], sa + out_off[4]);
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int k = 0; k < 5; ++k)
-                if (k < 4 || wave < 2) *reinterpret_cast<uint4*>(ob + (tid + 256 * k) * 16) = v[k];
+            pend_ob = reinterpret_cast<char*>(P_out + (size_t)cr * 16 * LAT_D);
         }
-        issued += wave < 2 ? 5 : 4;                   // the stores above
 #endif
         // ---- the next row's Qt: prove the prefetch landed, then (and only then) copy it.  With >= 3 tiles
         // the wait for tile 2 (requested after the prefetch) already proved it; shorter rows wait here
-        // (at most 2 tiles + 6 stores = 30 younger instructions).
+        // (at most 2 tiles = 24 younger loads).
         if (cnt < 3) wait_vm_newer(issued - mkq);
 #pragma unroll
         for (int s = 0; s < 6; ++s) asm volatile("" : "+v"(qn[s]));     // no copy may move above the wait
@@ -480,6 +498,7 @@ __global__ __launch_bounds__(256, 1) void latent_attn_kernel(LatentParams p) {
         for (int s = 0; s < 6; ++s) qf[s] = qn[s];
         cr += nblk;
     }
+    STORE_PENDING();                                  // the last row
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef MOCR_LAT_STAMPS
     if (P_dbg && blockIdx.x == 0 && tid == 0)
@@ -487,5 +506,6 @@ __global__ __launch_bounds__(256, 1) void latent_attn_kernel(LatentParams p) {
 #endif
 #undef STAMP
 #undef ISSUE_NEXT
+#undef STORE_PENDING
 #undef Q_PTR
 }

@@ -1,0 +1,184 @@
+// Fused query path of the latent decode attention (bf16, fat batches):
+//
+//     q_h  = x . Wq_h^T + bq_h                 [rows, 64]   per head h      (TF/models/bert/modeling_bert.py:151-166 / 218-230)
+//     Qt_h = bf16(q_h) . (Wk_h^T / 8)          [rows, 768]                  (the absorbed query, see kernels_latent.h)
+//
+// As two launches (gemm_dec_q: 16 us, gemm_dec_qt: 31 us at 4096 rows, four times per decode step) the second
+// GEMM has a single 64-deep K-tile per block: all prologue and epilogue, and its 75 MB of output are written at
+// 2.5 TB/s.  Here one block owns (128 rows, one head): phase 1 is an ordinary K = 768 GEMM for the 128 x 64
+// query tile, which goes to LDS as bf16 (the same rounding the two-launch path applies when it stores q);
+// phase 2 multiplies it by the six 128-row slices of Wk_h^T/8, double-buffered across the slices, and stores Qt
+// straight from the registers.  MFMA shape, K order and roundings are those of gemm_kernel's
+// bf16 path, so the result is bit-identical to the two-launch path.
+//
+// Both products use SWAPPED operands (weight fragment as A): a lane then holds four consecutive output columns
+// of one row - an 8-byte LDS store in phase 1, and after v_permlane16_swap a 16-byte global store in phase 2
+// (see gemm_wide_kernel).  LDS images are those of gemm_kernel: 128-byte rows, 16-byte chunk c of row r at
+// chunk c ^ ((r >> 1) & 7), swizzle applied on the DMA source address.
+#pragma once
+#include "common.h"
+
+struct QqtParams {
+    const bf16_t* x;      // [rows_pad][768] layer input (bf16)
+    const bf16_t* wq;     // [768][768] query weight, row n = output feature (head h: rows 64h .. 64h+63)
+    const float* bq;      // [768]
+    const bf16_t* wkT;    // [768 n][768]: column block 64h .. 64h+63 of row n = (Wk_h^T / 8)[:, n]
+    bf16_t* qt;           // [rows_pad][16][768]
+};
+
+#define QQT_LDS (2 * (128 + 64) * 128 + 128 * 128)      // phase-1 ring (2 x 24 KiB; phase 2: 2 x 16 KiB of it) + the q tile
+
+__global__ __launch_bounds__(256, 2) void dec_qqt_kernel(QqtParams p) {
+    constexpr int D = 768, KT = D / 64;                 // 12 K-tiles of 64 in phase 1
+    constexpr int A_BYTES = 128 * 128, STAGE = (128 + 64) * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const sQ = smem + 2 * STAGE;                  // [128 rows][64 dims] bf16, swizzled 128-B rows
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int m0 = blockIdx.x * 128, h = blockIdx.y;
+
+    // DMA pieces: 1 KiB = 8 rows x 128 B; lane -> row lane>>3, physical chunk lane&7 = logical chunk ^ ((row>>1)&7)
+    const int prow = lane >> 3, pchunk = lane & 7;
+    const char* const xb = reinterpret_cast<const char*>(p.x + (size_t)m0 * D);
+    const char* const wqb = reinterpret_cast<const char*>(p.wq + (size_t)(h * 64) * D);
+    auto stage1 = [&](int t, int buf) {
+        char* sa = smem + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                   // 16 pieces of x
+            const int pc = wave + 4 * i, row = pc * 8 + prow, c = pchunk ^ ((row >> 1) & 7);
+            glds16(xb + (size_t)row * (D * 2) + t * 128 + c * 16, sa + pc * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {                   // 8 pieces of Wq_h
+            const int pc = wave + 4 * i, row = pc * 8 + prow, c = pchunk ^ ((row >> 1) & 7);
+            glds16(wqb + (size_t)row * (D * 2) + t * 128 + c * 16, sa + A_BYTES + pc * 1024);
+        }
+    };
+
+    // ---------------- phase 1: q tile.  Wave (wm, wn): rows 64 wm .. +63, query dims 32 wn .. +31
+    f32x4 qa[2][4];      // [dim tile j][row tile i]: lane holds q[m = 16i + l15][d = 16j + 4 g4 + r]
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) qa[j][i][r] = 0.f;
+    stage1(0, 0);
+    for (int t = 0; t < KT; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + 1 < KT) stage1(t + 1, (t + 1) & 1);
+        const char* sa = smem + (t & 1) * STAGE;
+        const char* sb = sa + A_BYTES;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int c = 4 * s + g4;
+            bf16x8 fx[4], fw[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = wm * 64 + i * 16 + l15;
+                fx[i] = *(const bf16x8*)(sa + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = wn * 32 + j * 16 + l15;
+                fw[j] = *(const bf16x8*)(sb + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    qa[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fx[i], qa[j][i], 0, 0, 0);
+        }
+    }
+    // Wk^T slices of phase 2: LDS-DMA, double-buffered.  The wait for a slice is a FULL drain (vmcnt(0)), previous
+    // slice's global stores included: a counted s_waitcnt vmcnt(N) that lets YOUNGER STORES fly does not prove that
+    // an OLDER LDS-DMA has landed on this part (measured: with the weights cold in L2, vmcnt(8) in front of the 8
+    // younger stores let the MFMAs read a slice that was still arriving, about once in 40 launches; staging the
+    // slices through registers instead - ordinary loads do retire in order with stores - was correct but no faster
+    // than the two-launch path).
+    const char* const wkb = reinterpret_cast<const char*>(p.wkT + h * 64);
+    auto stage2 = [&](int nt2, int buf) {
+        char* sw = smem + buf * A_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                   // 16 pieces: rows 128 nt2 .. +127 of Wk^T, this head's 128-byte column block
+            const int pc = wave + 4 * i, row = pc * 8 + prow, c = pchunk ^ ((row >> 1) & 7);
+            glds16(wkb + (size_t)(nt2 * 128 + row) * (D * 2) + c * 16, sw + pc * 1024);
+        }
+    };
+    // q + bias -> bf16 -> sQ (8 bytes per lane and tile)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int d = wn * 32 + 16 * j + 4 * g4;
+        const float4 bv = *reinterpret_cast<const float4*>(p.bq + h * 64 + d);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = wm * 64 + 16 * i + l15;
+            const unsigned w0 = (unsigned)f2bf(qa[j][i][0] + bv.x) | ((unsigned)f2bf(qa[j][i][1] + bv.y) << 16);
+            const unsigned w1 = (unsigned)f2bf(qa[j][i][2] + bv.z) | ((unsigned)f2bf(qa[j][i][3] + bv.w) << 16);
+            *reinterpret_cast<uint2*>(sQ + row * 128 + (((d >> 3) ^ ((row >> 1) & 7)) << 4) + (d & 7) * 2) = make_uint2(w0, w1);
+        }
+    }
+    __syncthreads();                                    // every wave is past its last phase-1 fragment reads: the ring is free
+    stage2(0, 0);
+
+    // ---------------- phase 2: Qt tile = q tile . (Wk_h^T/8) slices.  Wave (wm, wn): rows 64 wm .. +63, columns 64 wn .. +63 of a slice
+    bf16x8 fq[2][4];     // q fragments of this wave's 64 rows, both 32-deep k-steps: the same for all six slices
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = wm * 64 + i * 16 + l15, c = 4 * s + g4;
+            fq[s][i] = *(const bf16x8*)(sQ + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+        }
+    bf16_t* const orow0 = p.qt + ((size_t)(m0 + wm * 64 + l15) * 16 + h) * D + wn * 64;
+    for (int nt2 = 0; nt2 < 6; ++nt2) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // slice nt2 landed (and the previous slice's stores acknowledged)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (nt2 + 1 < 6) stage2(nt2 + 1, (nt2 + 1) & 1);      // its buffer was last read one slice ago
+        const char* sw = smem + (nt2 & 1) * A_BYTES;
+        f32x4 acc[4][4];     // [column tile j][row tile i]
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[j][i][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 fw[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = wn * 64 + j * 16 + l15, c = 4 * s + g4;
+                fw[j] = *(const bf16x8*)(sw + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fq[s][i], acc[j][i], 0, 0, 0);
+        }
+        // stores: exactly 8 per lane (4 row tiles x 2 column-tile pairs), 16 bytes each
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bf16_t* orow = orow0 + (size_t)(16 * i) * 16 * D + nt2 * 128;
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp) {
+                unsigned x0 = (unsigned)f2bf(acc[2 * jp][i][0]) | ((unsigned)f2bf(acc[2 * jp][i][1]) << 16);
+                unsigned x1 = (unsigned)f2bf(acc[2 * jp][i][2]) | ((unsigned)f2bf(acc[2 * jp][i][3]) << 16);
+                unsigned y0 = (unsigned)f2bf(acc[2 * jp + 1][i][0]) | ((unsigned)f2bf(acc[2 * jp + 1][i][1]) << 16);
+                unsigned y1 = (unsigned)f2bf(acc[2 * jp + 1][i][2]) | ((unsigned)f2bf(acc[2 * jp + 1][i][3]) << 16);
+                {   // even 16-lane rows keep column tile 2jp and take the odd neighbour's half of it; odd rows keep 2jp+1
+                    auto s0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
+                    auto s1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
+                    x0 = s0[0]; y0 = s0[1]; x1 = s1[0]; y1 = s1[1];
+                }
+                const int ncol = 32 * jp + ((g4 & 1) ? 16 + 4 * (g4 - 1) : 4 * g4);
+                *reinterpret_cast<uint4*>(orow + ncol) = make_uint4(x0, x1, y0, y1);
+            }
+        }
+    }
+}

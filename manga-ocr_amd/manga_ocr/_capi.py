@@ -55,6 +55,7 @@ SYMBOLS = {
     "mocr_op_layernorm": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32]),
     "mocr_op_enc_attention": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32]),
     "mocr_op_latent_attention": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int64]),
+    "mocr_op_qqt": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32]),
     "mocr_profile_enable": (C.c_int, [_P, C.c_int32]),
     "mocr_profile_reset": (C.c_int, [_P]),
     "mocr_profile_get": (C.c_int, [_P, C.POINTER(MocrKernelStat), C.c_int32, C.POINTER(C.c_int32)]),

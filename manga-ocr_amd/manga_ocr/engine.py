@@ -171,6 +171,9 @@ class Engine:
         self._check(self.lib.mocr_op_latent_attention(self._h, _ptr(d_qt), _ptr(d_x), _ptr(d_out), n, length, x_batch_stride))
 
     # ------------------------------------------------------------------ per-kernel timing
+    def op_qqt(self, d_x, d_wq, d_bq, d_wkT, d_qt, n: int) -> None:
+        self._check(self.lib.mocr_op_qqt(self._h, _ptr(d_x), _ptr(d_wq), _ptr(d_bq), _ptr(d_wkT), _ptr(d_qt), n))
+
     def profile_enable(self, on: bool = True) -> None:
         self._check(self.lib.mocr_profile_enable(self._h, 1 if on else 0))
 

@@ -187,3 +187,28 @@ def test_latent_attention(L, n):
     err = np.abs(got - ref).max()
     report(f"latent attention L={L}: max abs err {err:.3e} (|ref| max {np.abs(ref).max():.2f})")
     assert np.isfinite(got).all() and err <= 3e-2
+
+
+@pytest.mark.parametrize("n", [128, 300, 1024])
+def test_fused_query_kernel(n):
+    """dec_qqt_kernel: Qt[m][h] = bf16(x[m] Wq_h^T + bq_h) . wkT_h for the 12 heads, against float64 numpy with the same
+    intermediate bf16 rounding of q."""
+    eng = engine("bf16")
+    rs = np.random.RandomState(n)
+    D, H = 768, 12
+    npad = (n + 127) // 128 * 128
+    x = bf16_round(rs.standard_normal((npad, D)).astype(np.float32))
+    wq = bf16_round((rs.standard_normal((D, D)) * 0.04).astype(np.float32))
+    bq = (rs.standard_normal(D) * 0.1).astype(np.float32)
+    wkT = bf16_round((rs.standard_normal((D, D)) * 0.04).astype(np.float32))      # [n][64h + k]
+    q = bf16_round((x.astype(np.float64) @ wq.astype(np.float64).T + bq).astype(np.float32)).astype(np.float64)
+    ref = np.einsum("mhk,nhk->mhn", q.reshape(npad, H, 64), wkT.astype(np.float64).reshape(D, H, 64))
+    dqt = torch.full((npad, 16, D), float("nan"), device="cuda", dtype=torch.bfloat16)
+    dx, dwq, dwk = _dev(x, "bf16"), _dev(wq, "bf16"), _dev(wkT, "bf16")
+    dbq = torch.from_numpy(bq).cuda()
+    torch.cuda.synchronize()
+    eng.op_qqt(dx, dwq, dbq, dwk, dqt, n)
+    got = dqt[:n, :H].float().cpu().numpy().astype(np.float64)
+    err = np.abs(got - ref[:n]).max() / np.abs(ref).max()
+    report(f"fused q->Qt kernel n={n}: max rel err {err:.3e}")
+    assert np.isfinite(got).all() and err <= 8e-3
