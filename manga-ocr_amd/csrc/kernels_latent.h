@@ -124,14 +124,14 @@ __device__ __forceinline__ void lds_read3_b128(uint4* o, unsigned a0, unsigned a
 // runs across sequence boundaries, so only the very first tile of a block waits for HBM.
 //
 // vmcnt bookkeeping.  LOADS (LDS-DMA and ordinary global loads) come back in issue order, so "load X has
-// landed" is s_waitcnt vmcnt(number of LOADS this wave issued after X).  STORES are deliberately NOT counted as
-// younger instructions: measured on this part (kernels_qqt.h), a vmcnt(N) that lets N younger stores fly does not
-// prove that an older LDS-DMA has landed - the stores' acknowledgements can overtake it.  An outstanding store
-// therefore only ever makes a wait longer, never shorter than it must be; and to keep it from making waits
-// longer in practice, a finished row's stores are issued right AFTER the next row's first tile wait (the row is
-// read back from its LDS staging into registers first), so they have a whole tile period before the next wait.
-// The wave keeps the load count at run time: `issued` (up to 12 global_load_lds per tile, 6 inline-asm loads per
-// Qt prefetch), and every ring slot remembers the count at
+// landed" is s_waitcnt vmcnt(number of LOADS this wave issued after X).  STORES must not be among the instructions
+// such a wait lets fly: measured on this part (kernels_qqt.h), vmcnt(N) with N younger stores in flight does not
+// prove that an older LDS-DMA has landed - the stores' acknowledgements can overtake it - and counting them out
+// instead makes every wait behind a store wait for its acknowledgement (4 us per row under load).  So the waves
+// are specialised: waves 0-2 request ALL the tile DMA (16 of a tile's 48 pieces each) and never store; wave 3
+// requests no DMA, never waits on a tile (the block's barrier covers it) and stores every finished row.  A wave
+// that waits on DMA thus has only loads in its queue.  The wave keeps their count at run time: `issued` (up to
+// 16 global_load_lds per tile, 6 inline-asm loads per Qt prefetch), and every ring slot remembers the count at
 // which its tile was requested.  The Qt loads are inline asm on purpose: an ordinary global load
 // beside LDS-DMA makes hipcc put s_waitcnt vmcnt(0) in front of its first use, which would drain the
 // ring once per tile (cdna_hip_programming.md §5, "Three .s-level traps" (b)).  Because the compiler
@@ -161,16 +161,16 @@ __device__ __forceinline__ void wait_vm_newer(int newer) {
 }
 #undef LAT_VM_CASE
 
-// request one tile: piece pc = wave + 4i (1 KiB = 64 consecutive 16-byte chunks of the tile image) for
-// pc < np.  A full tile is np = 48 pieces (12 DMA instructions per wave); a sequence's last tile asks only
-// for the pieces that hold its valid keys (src_off: this lane's 12 source offsets).  The branch is
-// wave-uniform; the caller adds lat_pieces_of(np, wave) to its VMEM count.
-__device__ __forceinline__ void lat_stage(const char* src, char* dst, const unsigned (&src_off)[12], int wave, int np) {
+// request one tile: DMA wave w (0..2) takes the pieces pc = w + 3i (1 KiB = 64 consecutive 16-byte chunks of the
+// tile image) with pc < np.  A full tile is np = 48 pieces (16 DMA instructions per DMA wave); a sequence's last tile
+// asks only for the pieces that hold its valid keys (src_off: this lane's 16 source offsets).  The branch is
+// wave-uniform; the caller adds lat_pieces_of(np, w) to its load count.
+__device__ __forceinline__ void lat_stage(const char* src, char* dst, const unsigned (&src_off)[16], int w, int np) {
 #pragma unroll
-    for (int i = 0; i < 12; ++i)
-        if (wave + 4 * i < np) glds16(src + src_off[i], dst + (wave + 4 * i) * 1024);
+    for (int i = 0; i < 16; ++i)
+        if (w + 3 * i < np) glds16(src + src_off[i], dst + (w + 3 * i) * 1024);
 }
-__device__ __forceinline__ int lat_pieces_of(int np, int wave) { return (np - wave + 3) >> 2; }   // #i in 0..11 with wave+4i < np (np <= 48)
+__device__ __forceinline__ int lat_pieces_of(int np, int w) { return (np - w + 2) / 3; }   // #i in 0..15 with w+3i < np (np <= 48)
 
 __global__ __launch_bounds__(256, 1) void latent_attn_kernel(LatentParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -212,10 +212,10 @@ __global__ __launch_bounds__(256, 1) void latent_attn_kernel(LatentParams p) {
 
     // DMA source offsets of this lane for the 12 pieces a wave copies per tile: piece pc covers the
     // linear 16-byte chunks 64*pc .. 64*pc+63 of the tile image
-    unsigned src_off[12];
+    unsigned src_off[16];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
-        const int gch = 64 * (wave + 4 * i) + lane;      // 0 .. 3071
+    for (int i = 0; i < 16; ++i) {
+        const int gch = 64 * ((wave < 3 ? wave : 0) + 3 * i) + lane;      // 0 .. 3071 (wave 3 requests nothing)
         const int r = gch / 96, cp = gch - r * 96;       // key row, physical chunk
         const int c = (cp & ~15) | ((cp ^ r) & 15);      // logical chunk stored there
         src_off[i] = (unsigned)(r * (LAT_D * 2) + c * 16);
@@ -238,13 +238,6 @@ __global__ __launch_bounds__(256, 1) void latent_attn_kernel(LatentParams p) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int s = 0; s < 6; ++s) s_off[6 * j + s] = lat_off(16 * j + l15, 24 * wave + 4 * s + g);
-    // LDS offsets (inside the output staging image) of the 16-byte chunks tid + 256k this thread stores
-    unsigned out_off[5];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        const int idx = tid + 256 * k, h = idx / 96;     // (head, chunk of its 1536-B row); h = 12, 13 for the unused k = 4 of waves 2, 3
-        out_off[k] = (unsigned)(h * LAT_OUT_HS + (idx - 96 * h) * 16);
-    }
     const unsigned smem_base = lds_addr(smem);
     // A operand of the S product: Qt[head = lane&15][192*wave + 32*s + 8*g .. +7]
     // (the MFMA rows 12..15 are padding: their lanes re-read heads 0..3 - same cache lines, no extra
@@ -268,9 +261,11 @@ __global__ __launch_bounds__(256, 1) void latent_attn_kernel(LatentParams p) {
     do {                                                                                                          \
         if (ir < P_rows) {                                                                                        \
             const int np_ = it == cnt - 1 ? np_last : 48;                                                         \
-            lat_stage(reinterpret_cast<const char*>(P_x + (size_t)ir * P_xstride) + (size_t)it * LAT_TILE_BYTES,   \
-                      smem + islot * LAT_TILE_BYTES, src_off, wave, np_);                                         \
-            issued += lat_pieces_of(np_, wave);                                                                   \
+            if (wave < 3) {                                                                                       \
+                lat_stage(reinterpret_cast<const char*>(P_x + (size_t)ir * P_xstride) + (size_t)it * LAT_TILE_BYTES, \
+                          smem + islot * LAT_TILE_BYTES, src_off, wave, np_);                                     \
+                issued += lat_pieces_of(np_, wave);                                                               \
+            }                                                                                                     \
             if (islot == 0) mk0 = issued; else if (islot == 1) mk1 = issued; else mk2 = issued;                   \
             islot = islot + 1 == LAT_NST ? 0 : islot + 1;                                                         \
             if (++it == cnt) { ir += nblk; it = 0; }                                                              \
@@ -290,19 +285,6 @@ __global__ __launch_bounds__(256, 1) void latent_attn_kernel(LatentParams p) {
     ISSUE_NEXT();
     ISSUE_NEXT();
     int slot = 0;
-    // the previous row's output, read back from its staging image, waiting to be stored (see the header)
-    uint4 pend[5];
-    char* pend_ob = nullptr;
-#pragma unroll
-    for (int k = 0; k < 5; ++k) pend[k] = make_uint4(0, 0, 0, 0);
-#define STORE_PENDING()                                                                                          \
-    do {                                                                                                          \
-        if (pend_ob) {                                                                                            \
-            _Pragma("unroll") for (int k = 0; k < 5; ++k)                                                         \
-                if (k < 4 || wave < 2) *reinterpret_cast<uint4*>(pend_ob + (tid + 256 * k) * 16) = pend[k];       \
-            pend_ob = nullptr;                                                                                    \
-        }                                                                                                         \
-    } while (0)
 
     while (cr < P_rows) {
         // Qt of the next row (L2-resident, 6 loads per lane): requested now, consumed at the row's end
@@ -323,15 +305,10 @@ __global__ __launch_bounds__(256, 1) void latent_attn_kernel(LatentParams p) {
         for (int t = 0; t < cnt; ++t) {
             STAMP(5)   // everything since the last stamp of the previous tile (loop overhead, row end)
             // the tile of `slot` has landed: allow exactly the instructions issued after its request
-            wait_vm_newer(issued - (slot == 0 ? mk0 : slot == 1 ? mk1 : mk2));
+            if (wave < 3) wait_vm_newer(issued - (slot == 0 ? mk0 : slot == 1 ? mk1 : mk2));
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             ISSUE_NEXT();                         // refills the slot every wave has finished reading
-            if (t == 0) {                         // the previous row's stores: a whole tile period until the next wait
-                __builtin_amdgcn_sched_barrier(0);
-                STORE_PENDING();
-                __builtin_amdgcn_sched_barrier(0);
-            }
             const char* xt = smem + slot * LAT_TILE_BYTES;
             slot = slot + 1 == LAT_NST ? 0 : slot + 1;
             STAMP(0)   // wait + barrier + DMA issue
@@ -478,27 +455,41 @@ __global__ __launch_bounds__(256, 1) void latent_attn_kernel(LatentParams p) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         {
-            // 1152 chunks of 16 B = 12 heads x 1536 B, contiguous in the output: thread tid moves chunks
-            // tid + 256k, k = 0..3, and chunk tid + 1024 (waves 0 and 1 only).  Read back now (the slot is refilled
-            // at the next tile's top), stored after the next row's first tile wait.
-            const unsigned sa = lds_addr(stg);
-            lds_read3_b128(pend, sa + out_off[0], sa + out_off[1], sa + out_off[2]);
-            lds_read2_b128(pend + 3, sa + out_off[3], sa + out_off[4]);
-            __builtin_amdgcn_sched_barrier(0);
-            pend_ob = reinterpret_cast<char*>(P_out + (size_t)cr * 16 * LAT_D);
+            // 1152 chunks of 16 B = 12 heads x 1536 B, contiguous in the output: wave 3 moves them all, lane l the
+            // chunks l + 64k, k = 0..17, six at a time.  Its queue holds only its own Qt prefetch and stores: the
+            // vmcnt(0) in front proves the prefetch (and acknowledges the previous row's stores, a row old by now).
+            if (wave == 3) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                char* ob = reinterpret_cast<char*>(P_out + (size_t)cr * 16 * LAT_D);
+                const unsigned sa = lds_addr(stg);
+#pragma unroll
+                for (int b3 = 0; b3 < 3; ++b3) {
+                    uint4 v[6];
+                    unsigned ad[6];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        const int idx = lane + 64 * (6 * b3 + k), hh = idx / 96;
+                        ad[k] = sa + (unsigned)(hh * LAT_OUT_HS + (idx - 96 * hh) * 16);
+                    }
+                    lds_read3_b128(v, ad[0], ad[1], ad[2]);
+                    lds_read3_b128(v + 3, ad[3], ad[4], ad[5]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) *reinterpret_cast<uint4*>(ob + (lane + 64 * (6 * b3 + k)) * 16) = v[k];
+                }
+            }
         }
 #endif
         // ---- the next row's Qt: prove the prefetch landed, then (and only then) copy it.  With >= 3 tiles
         // the wait for tile 2 (requested after the prefetch) already proved it; shorter rows wait here
         // (at most 2 tiles = 24 younger loads).
-        if (cnt < 3) wait_vm_newer(issued - mkq);
+        if (cnt < 3 && wave < 3) wait_vm_newer(issued - mkq);
 #pragma unroll
         for (int s = 0; s < 6; ++s) asm volatile("" : "+v"(qn[s]));     // no copy may move above the wait
 #pragma unroll
         for (int s = 0; s < 6; ++s) qf[s] = qn[s];
         cr += nblk;
     }
-    STORE_PENDING();                                  // the last row
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef MOCR_LAT_STAMPS
     if (P_dbg && blockIdx.x == 0 && tid == 0)
@@ -506,6 +497,5 @@ __global__ __launch_bounds__(256, 1) void latent_attn_kernel(LatentParams p) {
 #endif
 #undef STAMP
 #undef ISSUE_NEXT
-#undef STORE_PENDING
 #undef Q_PTR
 }
