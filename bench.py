@@ -65,13 +65,13 @@ def cpu_baseline(args, weights):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=128)
-    ap.add_argument("--warmup", type=int, default=128)
+    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--warmup", type=int, default=256)
     ap.add_argument("--batch", type=int, default=64, help="crops per GPU per step (BASELINE configs[1]: 64)")
     ap.add_argument("--max-len", type=int, default=300)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--lanes", type=int, default=2, help="internal batches the engine keeps in flight (streams + workspaces)")
-    ap.add_argument("--max-batch", type=int, default=4096, help="rows of one internal engine batch: submitted steps are merged up to this")
+    ap.add_argument("--max-batch", type=int, default=8192, help="rows of one internal engine batch: submitted steps are merged up to this")
     ap.add_argument("--cpu-sample", type=int, default=96, help="crops the CPU baseline (oracle) decodes: ~12 s on 16 host threads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
@@ -168,7 +168,7 @@ def main():
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
             # the PMC passes were taken on one merged batch of pm["rows"] rows; both latent-attention launches
             # (self / cross) are the same kernel symbol, so the average is over both
-            if k0["kernel"].startswith("lat_attn") and args.dtype == "bf16" and args.max_len == 300 and pm.get("rows") == args.max_batch:
+            if k0["kernel"].startswith("lat_attn") and args.dtype == "bf16" and args.max_len == 300 and pm.get("rows") == psteps * B:
                 hit = [v for k, v in pm["kernels"].items() if "latent_attn_kernel" in k]
                 if hit:
                     traffic = sum(v["traffic_bytes"] * v["launches"] for v in hit) / sum(v["launches"] for v in hit)
