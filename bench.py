@@ -91,7 +91,10 @@ def main():
         args.gpus = world
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    # MOCR_BENCH_FORCE_DIST=1: take the collective path (process group, barrier, all-gather, max over ranks) even with
+    # one rank - a rehearsal of the N > 1 code on a one-GPU box
+    use_dist = world > 1 or bool(os.environ.get("MOCR_BENCH_FORCE_DIST"))
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
@@ -107,7 +110,7 @@ def main():
     K = max(args.steps, args.warmup, 1)
     d_ids = torch.zeros((K, B, L), dtype=torch.int32, device="cuda")      # one output block per step
     d_len = torch.zeros((K, B), dtype=torch.int32, device="cuda")
-    d_all = torch.zeros((world * K, B, L), dtype=torch.int32, device="cuda") if world > 1 else None
+    d_all = torch.zeros((world * K, B, L), dtype=torch.int32, device="cuda") if use_dist else None
     torch.cuda.synchronize()
 
     def run(nsteps):
@@ -116,12 +119,12 @@ def main():
         for i in range(nsteps):
             eng.recognize_device(d_gray, B, d_ids[i], d_len[i])
         eng.synchronize()
-        if world > 1:
+        if use_dist:
             dist.all_gather_into_tensor(d_all, d_ids)
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -131,7 +134,7 @@ def main():
     run(args.steps)
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -195,7 +198,7 @@ def main():
             "roofline": roof, "cpu_baseline": cpu, "kernels": kernels[:24],
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
     eng.close()
 
