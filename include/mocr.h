@@ -50,9 +50,7 @@ enum {
     MOCR_FLAG_NO_EARLY_EXIT = 1 << 2,    /* always run max_len-1 decode steps */
     MOCR_FLAG_CLASSIC_ATTENTION = 1 << 3, /* bf16: projected K/V caches instead of the latent (absorbed) decode attention */
     MOCR_FLAG_NO_FUSED_ARGMAX = 1 << 4,   /* always write the logits and take the argmax in the token kernel */
-    MOCR_FLAG_FUSED_QQT = 1 << 5          /* latent attention, fat batches: query and absorbed query from ONE launch (kernels_qqt.h).
-                                           * Opt-in: bit-identical to the two-launch path on its own, but with two lanes in flight its
-                                           * results were not reproducible run to run (r01, cause not found) */
+    MOCR_FLAG_NO_FUSED_QQT = 1 << 5       /* latent attention: query and absorbed query as two GEMM launches even for fat batches */
 };
 
 typedef struct mocr_engine mocr_engine;

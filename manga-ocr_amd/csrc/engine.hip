@@ -562,18 +562,16 @@ void latent_block(mocr_engine* e, bool self, int layer, int n, int t, const void
                   const void* wkT, const void* wv, const float* bv) {
     using T = bf16_t;
     const int D = e->D;
-    // fat batches, opt-in (MOCR_FLAG_FUSED_QQT or MOCR_DEC_QQT=1): q and Qt in one launch (kernels_qqt.h), 37 us instead of
-    // 16 + 31 at 4096 rows.  NOT the default: alone (one lane) it is bit-identical to the two-launch path and
-    // reproducible, but with two lanes in flight the decoded ids differed from run to run (r01) unless the launch asked
-    // for >= 80 KiB of LDS instead of the 64 KiB it uses - a co-residency effect whose cause was not found.
-    static const int qqt_env = env_int("MOCR_DEC_QQT", 0);
-    if ((qqt_env || (e->cfg.flags & MOCR_FLAG_FUSED_QQT)) && n >= 1024 && D == 768 && e->H == 12) {
+    // fat batches: q and Qt in one launch (kernels_qqt.h), 37 us instead of 16 + 31 at 4096 rows; bit-identical to the
+    // two-launch path.  MOCR_DEC_QQT_ROWS = rows from which it is used (0 = never)
+    static const int qqt_rows = env_int("MOCR_DEC_QQT_ROWS", 1024);
+    if (qqt_rows > 0 && n >= qqt_rows && D == 768 && e->H == 12 && !(e->cfg.flags & MOCR_FLAG_NO_FUSED_QQT)) {
         QqtParams q{};
         q.x = reinterpret_cast<const bf16_t*>(xin); q.wq = reinterpret_cast<const bf16_t*>(wq); q.bq = bq;
         q.wkT = reinterpret_cast<const bf16_t*>(wkT); q.qt = reinterpret_cast<bf16_t*>(e->qt);
         {
             ProfScope ps(e, "dec_qqt", 4.0 * n * D * D, (double)n * D * 2 + 2.0 * D * D * 2 + (double)n * e->H * D * 2);
-            static const int qqt_lds = env_int("MOCR_QQT_LDS", 80 * 1024);      // see above (the kernel itself uses QQT_LDS = 64 KiB)
+            static const int qqt_lds = env_int("MOCR_QQT_LDS", QQT_LDS);
             hipLaunchKernelGGL(dec_qqt_kernel, dim3((n + 127) / 128, e->H), dim3(256), qqt_lds, e->stream, q);
             HIPCHECK(hipGetLastError());
         }
@@ -1511,7 +1509,7 @@ int mocr_op_qqt(mocr_engine* e, const void* d_x, const void* d_wq, const float* 
         q.x = reinterpret_cast<const bf16_t*>(d_x); q.wq = reinterpret_cast<const bf16_t*>(d_wq); q.bq = d_bq;
         q.wkT = reinterpret_cast<const bf16_t*>(d_wkT); q.qt = reinterpret_cast<bf16_t*>(d_qt);
         ProfScope ps(e, "op_qqt", 4.0 * n * 768 * 768, 0);
-        hipLaunchKernelGGL(dec_qqt_kernel, dim3((n + 127) / 128, 12), dim3(256), QQT_LDS, e->stream, q);
+        hipLaunchKernelGGL(dec_qqt_kernel, dim3((n + 127) / 128, 12), dim3(256), env_int("MOCR_QQT_LDS", QQT_LDS), e->stream, q);
         HIPCHECK(hipGetLastError());
         HIPCHECK(hipStreamSynchronize(e->stream));
     });

@@ -273,6 +273,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
             static_assert(NST == 4, "ring depth");
             if (newer >= 2) wait_vmcnt<2 * LPT>(); else if (newer == 1) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
         }
+        // Also every LDS read this wave has issued must be BACK before the barrier: hipcc sinks the last MFMAs of the
+        // previous K-tile (and the lgkmcnt wait for their fragments) below it, and behind the barrier the slot those
+        // reads come from is handed to the DMA.  Under LDS contention (several blocks per CU) such a read has been seen
+        // to lose that race (kernels_qqt.h, r01).
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (t + NST - 1 < nt) stage(t + NST - 1, (t + NST - 1) % NST);
@@ -457,8 +462,8 @@ __global__ __launch_bounds__(256, 1) void gemm256_kernel(GemmParams p) {
     if (nt > 1) stage(1, 1);
     for (int t = 0; t < nt; ++t) {
         // tile t landed: only the newest tile (if any) may still be in flight
-        if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");     // lgkmcnt: see gemm_kernel
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         // every wave is past its reads of tile t-1, so its ring slot can be refilled with tile t+2

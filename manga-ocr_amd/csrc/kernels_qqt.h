@@ -66,7 +66,9 @@ __global__ __launch_bounds__(256, 2) void dec_qqt_kernel(QqtParams p) {
             for (int r = 0; r < 4; ++r) qa[j][i][r] = 0.f;
     stage1(0, 0);
     for (int t = 0; t < KT; ++t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // lgkmcnt(0) too: hipcc sinks the last MFMAs of the previous K-tile (and the wait for their fragments) below
+        // this barrier, and behind it the buffer those fragment reads come from is handed to the DMA
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (t + 1 < KT) stage1(t + 1, (t + 1) & 1);
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void dec_qqt_kernel(QqtParams p) {
         }
     bf16_t* const orow0 = p.qt + ((size_t)(m0 + wm * 64 + l15) * 16 + h) * D + wn * 64;
     for (int nt2 = 0; nt2 < 6; ++nt2) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // slice nt2 landed (and the previous slice's stores acknowledged)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // slice nt2 landed (and the previous slice's stores acknowledged)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (nt2 + 1 < 6) stage2(nt2 + 1, (nt2 + 1) & 1);      // its buffer was last read one slice ago

@@ -244,11 +244,11 @@ def test_fused_lm_head_argmax_equals_logits_argmax():
 
 
 def test_fused_query_kernel_equals_two_gemm_path():
-    """>= 1024 rows, opt-in (flag 32): q and the absorbed query Qt come from one launch (kernels_qqt.h); same MFMA shape,
-    K order and roundings as the default two-GEMM path, so the token ids - and the lengths - must be identical."""
+    """>= 1024 rows: q and the absorbed query Qt come from one launch (kernels_qqt.h); same MFMA shape, K order and
+    roundings as the two-GEMM path (flag 32), so the token ids - and the lengths - must be identical."""
     gray = crops(78, 1024)
-    a = engine("bf16", max_batch=1024, flags=32)
-    b = engine("bf16", max_batch=1024)
+    a = engine("bf16", max_batch=1024)
+    b = engine("bf16", max_batch=1024, flags=32)
     ids_a, len_a = a.recognize_gray(gray, max_len=48)
     ids_b, len_b = b.recognize_gray(gray, max_len=48)
     np.testing.assert_array_equal(ids_a, ids_b)
@@ -281,7 +281,8 @@ def test_fat_batch_is_reproducible_and_agrees_with_a_small_batch():
 
 def test_two_lanes_in_flight_are_reproducible():
     """Two merged 2048-row batches decoding at the same time (kernels of both lanes share the CUs): the same queue
-    submitted twice must give identical ids - the check that exposed a co-residency effect of the fused query kernel."""
+    submitted twice must give identical ids - the check that exposed an LDS read still in flight behind a barrier
+    (kernels_qqt.h / gemm_kernel: lgkmcnt(0) in front of the K-loop barrier)."""
     import torch
     k, b, n_len = 64, 64, 300
     gray = crops(91, k * b).reshape(k, b, 224, 224)
