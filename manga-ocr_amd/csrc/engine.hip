@@ -129,7 +129,10 @@ struct mocr_engine : LaneCtx {
     std::string err;
     std::mutex mu;
     bool committed = false;
-    bool latent = false;            // bf16 engines: latent (absorbed) decode attention
+    bool latent = false;            // bf16 engines: latent (absorbed) decode attention ...
+    int classic_rows = 0;           // ... for batches of more than this many rows; smaller ones use the classic kernels
+    int Bc = 0;                     // rows the classic K/V buffers are sized for
+    bool use_latent(int n) const { return latent && n > classic_rows; }
     std::map<std::string, std::vector<float>> host_w;
     std::map<std::string, std::vector<int64_t>> host_shape;
     std::vector<void*> allocs;
@@ -485,7 +488,7 @@ void dec_token(mocr_engine* e, const DecState& st, int nslab, int n, int ncand =
     ProfScope ps(e, FIRST ? "dec_token_first" : "dec_token", 0, FIRST ? 0.0 : (double)n * e->V * 4 * nslab);
     hipLaunchKernelGGL((dec_token_kernel<T, 768, FIRST>), dim3(n), dim3(256), 0, e->stream, e->slabs, nslab,
                        (long long)e->Bp * e->V, w.bv, e->V, st, w.word, w.type0, w.posd, w.embg, w.embb, e->x_f32,
-                       reinterpret_cast<T*>(e->x_t), e->cfg.ln_eps, e->latent ? reinterpret_cast<T*>(e->xcache) : nullptr,
+                       reinterpret_cast<T*>(e->x_t), e->cfg.ln_eps, e->use_latent(n) ? reinterpret_cast<T*>(e->xcache) : nullptr,
                        (long long)e->cfg.max_len * e->D, ncand ? e->cand_val : nullptr, ncand ? e->cand_idx : nullptr, ncand);
     HIPCHECK(hipGetLastError());
 }
@@ -499,7 +502,7 @@ void dec_attn(mocr_engine* e, int layer, int nslab, int n, const float* bias, in
     p.slab_stride = (long long)e->Bp * p.ldq;
     p.bias = bias;
     if (SELF) {
-        const size_t per_layer = (size_t)e->Bp * H * e->cfg.max_len * 64;
+        const size_t per_layer = (size_t)e->Bc * H * e->cfg.max_len * 64;
         p.kbase = reinterpret_cast<char*>(e->kcache) + (size_t)layer * per_layer * sizeof(T);
         p.vbase = reinterpret_cast<char*>(e->vcache) + (size_t)layer * per_layer * sizeof(T);
         p.kv_batch_stride = (long long)H * e->cfg.max_len * 64;
@@ -601,7 +604,7 @@ void decode_step(mocr_engine* e, const DecState& st, int n, int t) {
         const DecLayerW& L = w.dec[l];
         int ns;
         const size_t esz = sizeof(T);
-        if (e->latent) {
+        if (e->use_latent(n)) {
             latent_block(e, true, l, n, t, xin, L.wqkv, L.bqkv, L.wkT_s, reinterpret_cast<const char*>(L.wqkv) + (size_t)2 * D * D * esz,
                          L.bqkv + 2 * D);
         } else {
@@ -610,7 +613,7 @@ void decode_step(mocr_engine* e, const DecState& st, int n, int t) {
         }
         ns = dec_gemm<T>(e, "gemm_dec_proj", e->ctx_t, D, L.wo, D, D, n);
         dec_add_ln<T>(e, ns, D, L.bo, xres, L.ln1g, L.ln1b, e->a_f32, e->a_t, n, false);
-        if (e->latent) {
+        if (e->use_latent(n)) {
             latent_block(e, false, l, n, t, e->a_t, L.wqc, L.bqc, L.wkT_c,
                          reinterpret_cast<const char*>(w.wckv) + (size_t)(2 * l + 1) * D * D * esz, w.bckv + (2 * l + 1) * D);
         } else {
@@ -630,7 +633,7 @@ void decode_step(mocr_engine* e, const DecState& st, int n, int t) {
         }
         ns = dec_gemm<T>(e, "gemm_dec_fc2", e->h_t, F, L.w2, D, F, n);
         dec_add_ln<T>(e, ns, D, L.b2, e->c_f32, L.ln3g, L.ln3b, e->x_f32, e->x_t, n, false,
-                      (e->latent && l + 1 < e->cfg.dec_layers) ? l + 1 : -1);
+                      (e->use_latent(n) && l + 1 < e->cfg.dec_layers) ? l + 1 : -1);
         xin = e->x_t; xres = e->x_f32;
     }
     int ns = dec_gemm<T>(e, "gemm_dec_proj", e->x_t, D, w.wt, D, D, n);
@@ -766,7 +769,7 @@ void start_batch(mocr_engine* e, Lane& L) {
         row0 += j.n;
     }
     run_encoder<T>(e, e->d_in, L.n);
-    if (!e->latent) run_cross_kv<T>(e, L.n);
+    if (!e->use_latent(L.n)) run_cross_kv<T>(e, L.n);
     // rows read pad_id (= 0) beyond what the loop writes
     HIPCHECK(hipMemsetAsync(e->ids, 0, (size_t)L.n * e->cfg.max_len * sizeof(int), e->stream));
     DecState st = make_state(e, L.max_len, nullptr, 0, nullptr);
@@ -1056,9 +1059,11 @@ void allocate_lane(mocr_engine* e, int lane_id) {
         e->qt = e->dalloc<char>(Bp * 16 * D * esz);
         e->et = e->dalloc<char>(Bp * 16 * D * esz);
         e->xcache = e->dalloc<char>(((size_t)c.dec_layers * Bp * c.max_len + 64) * D * esz);
-    } else {
-        e->CKV = e->dalloc<char>(Mp * (size_t)e->NCKV * esz);
-        const size_t cache = (size_t)c.dec_layers * Bp * e->H * c.max_len * 64 * esz;
+    }
+    if (e->Bc > 0) {      // classic K/V: the whole engine (fp32 / MOCR_FLAG_CLASSIC_ATTENTION) or its small batches
+        const size_t Mc = (size_t)round_up(e->Bc * e->S, 256) + 256;
+        e->CKV = e->dalloc<char>(Mc * (size_t)e->NCKV * esz);
+        const size_t cache = (size_t)c.dec_layers * e->Bc * e->H * c.max_len * 64 * esz;
         e->kcache = e->dalloc<char>(cache);
         e->vcache = e->dalloc<char>(cache);
     }
@@ -1077,6 +1082,11 @@ void allocate_lane(mocr_engine* e, int lane_id) {
 void allocate_lanes(mocr_engine* e) {
     compute_geometry(e);
     e->latent = e->cfg.dtype == MOCR_BF16 && !(e->cfg.flags & MOCR_FLAG_CLASSIC_ATTENTION);
+    // Small batches of a latent engine take the classic kernels: the persistent latent kernel walks a sequence's key
+    // tiles serially on ONE CU (~20 us per call whatever the batch), the classic one spreads a row over 12 blocks.
+    // Measured (r01, 300 tokens): 8 rows 36 vs 73 ms, 64 rows 50 vs 80 ms, 256 rows 111 vs 116 ms.
+    e->classic_rows = !e->latent ? 0 : (e->cfg.flags & MOCR_FLAG_LATENT_ALWAYS) ? 0 : std::min(env_int("MOCR_CLASSIC_ROWS", 128), e->cfg.max_batch);
+    e->Bc = e->latent ? e->classic_rows : e->Bp;
     const int nl = std::max(1, std::min(16, (int)e->cfg.lanes));
     e->lanes.resize(nl);
     for (int i = 0; i < nl; ++i) {
@@ -1419,7 +1429,7 @@ int mocr_decode_logits(mocr_engine* e, const void* d_gray, int32_t n, const int3
         dispatch(e, [&](auto tag) {
             using T_ = decltype(tag);
             run_encoder<T_>(e, g, n);
-            if (!e->latent) run_cross_kv<T_>(e, n);
+            if (!e->use_latent(n)) run_cross_kv<T_>(e, n);
             run_decode_forced<T_>(e, n, e->forced, T, e->logits_dbg);
         });
         HIPCHECK(hipMemcpyAsync(h_logits, e->logits_dbg, lcount * 4, hipMemcpyDeviceToHost, e->stream));

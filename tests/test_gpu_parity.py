@@ -300,3 +300,17 @@ def test_two_lanes_in_flight_are_reproducible():
         outs.append(ids.cpu().numpy())
     np.testing.assert_array_equal(outs[0], outs[1])
     report("two lanes x 2048 rows, 300 tokens: repeat run identical")
+
+
+def test_small_batches_take_the_classic_kernels_and_fat_ones_the_latent():
+    """The product engine chooses per batch: <= 128 rows classic (half the step latency), more rows latent.  Same
+    kernels as the engines that are forced one way or the other, so the ids are identical to theirs."""
+    auto = engine("bf16", max_batch=256, auto_path=True)
+    classic = engine("bf16", max_batch=256, flags=8)
+    latent = engine("bf16", max_batch=256)
+    small, fat = crops(92, 8), crops(93, 200)
+    np.testing.assert_array_equal(auto.recognize_gray(small, max_len=120)[0], classic.recognize_gray(small, max_len=120)[0])
+    np.testing.assert_array_equal(auto.recognize_gray(fat, max_len=60)[0], latent.recognize_gray(fat, max_len=60)[0])
+    # and both kinds interleaved on one engine (the K/V caches of the two paths are separate buffers)
+    np.testing.assert_array_equal(auto.recognize_gray(small, max_len=120)[0], classic.recognize_gray(small, max_len=120)[0])
+    report("auto path: 8 rows == classic engine, 200 rows == latent engine (ids identical)")
