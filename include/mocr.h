@@ -51,7 +51,7 @@ enum {
     MOCR_FLAG_CLASSIC_ATTENTION = 1 << 3, /* bf16: projected K/V caches instead of the latent (absorbed) decode attention */
     MOCR_FLAG_NO_FUSED_ARGMAX = 1 << 4,   /* always write the logits and take the argmax in the token kernel */
     MOCR_FLAG_NO_FUSED_QQT = 1 << 5,      /* latent attention: query and absorbed query as two GEMM launches even for fat batches */
-    MOCR_FLAG_LATENT_ALWAYS = 1 << 6      /* bf16: latent attention for every batch size (default: batches of <= 128 rows take the
+    MOCR_FLAG_LATENT_ALWAYS = 1 << 6      /* bf16: latent attention for every batch size (default: batches of <= 256 rows take the
                                            * classic projected-K/V kernels, whose grid - one block per (row, head) - has half the
                                            * step latency there: 50 instead of 80 ms for 64 crops) */
 };

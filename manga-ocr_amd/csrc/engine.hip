@@ -1085,7 +1085,7 @@ void allocate_lanes(mocr_engine* e) {
     // Small batches of a latent engine take the classic kernels: the persistent latent kernel walks a sequence's key
     // tiles serially on ONE CU (~20 us per call whatever the batch), the classic one spreads a row over 12 blocks.
     // Measured (r01, 300 tokens): 8 rows 36 vs 73 ms, 64 rows 50 vs 80 ms, 256 rows 111 vs 116 ms.
-    e->classic_rows = !e->latent ? 0 : (e->cfg.flags & MOCR_FLAG_LATENT_ALWAYS) ? 0 : std::min(env_int("MOCR_CLASSIC_ROWS", 128), e->cfg.max_batch);
+    e->classic_rows = !e->latent ? 0 : (e->cfg.flags & MOCR_FLAG_LATENT_ALWAYS) ? 0 : std::min(env_int("MOCR_CLASSIC_ROWS", 256), e->cfg.max_batch);
     e->Bc = e->latent ? e->classic_rows : e->Bp;
     const int nl = std::max(1, std::min(16, (int)e->cfg.lanes));
     e->lanes.resize(nl);
