@@ -118,10 +118,29 @@ typedef struct mocr_image {
     const uint8_t* data;
     int32_t height, width;
     int64_t row_stride;
-    int32_t channels;
+    int32_t channels;   /* 1 = L, 3 = RGB, MOCR_CHANNELS_BGR = 3 bytes per pixel in OpenCV's B,G,R order */
 } mocr_image;
+/* BGR pixels as the reference's crop tools and pages hold them (`cropped_cv_img`, `cv_image`: src/ui/main_window.py:6431,
+ * src/core/workers.py:461): the BGR -> RGB swap of src/ui/main_window.py:9800 is folded into the luminance conversion. */
+#define MOCR_CHANNELS_BGR (-3)
 /* out_ids [n, max_len] int32, out_len [n] int32 (host).  Blocking, thread-safe; n may exceed max_batch. */
 int mocr_recognize_images(mocr_engine* e, const mocr_image* images, int32_t n, int32_t* out_ids, int32_t* out_len);
+/* THE HOT PATH for the Text-detect callers: whole pages plus the bounding
+ * rectangles of the regions a detector found on them, replacing the serial loop of `_collect_manga_detections` ->
+ * `_recognize_polygon` -> `perform_ocr` (src/ui/main_window.py:9462-9476, 9530-9549, 9774-9803) and, over several
+ * pages, of `AutoDetectorWorker.run` (src/core/workers.py:448-482).  Every page is uploaded ONCE; each region's crop -
+ * its rectangle grown by int(max(w, h) * 0.08) on every side and clipped to the page, the rule of
+ * src/ui/main_window.py:9533-9537 - is cut on the device by the resize kernel's descriptor (offset + page stride), and
+ * all regions of all pages decode as one job queue.  A region that leaves no more than a 1-pixel sliver gets
+ * out_len = 0 and a row of pad_id (the reference returns '' for it without calling the recogniser, :9538-9539).
+ * region.{x, y, width, height} = QPolygon.boundingRect() of the detected polygon, in page pixels. */
+typedef struct mocr_region {
+    int32_t page;                /* index into pages[] */
+    int32_t x, y, width, height;
+} mocr_region;
+int mocr_recognize_regions(mocr_engine* e, const mocr_image* pages, int32_t n_pages, const mocr_region* regions,
+                           int32_t n_regions, int32_t* out_ids, int32_t* out_len);
+
 /* Preprocessing only (test hook): out_gray [n, image_size, image_size] uint8 (host) = the plane the encoder sees
  * in each of its three equal input channels before the 1/255 and (x - 0.5)/0.5 scaling. */
 int mocr_preprocess(mocr_engine* e, const mocr_image* images, int32_t n, uint8_t* out_gray);
@@ -164,6 +183,11 @@ int mocr_op_latent_attention(mocr_engine* e, const void* d_qt, const void* d_x, 
  * d_wq [768,768] bf16, d_bq [768] f32, d_wkT [768,768] bf16 (row n, column 64h+k = Wk_h[k][n]/8), d_qt [rows_pad,16,768] bf16:
  * d_qt[m][h] = bf16(x[m] . Wq_h^T + bq_h) . wkT_h   for the 12 heads. */
 int mocr_op_qqt(mocr_engine* e, const void* d_x, const void* d_wq, const float* d_bq, const void* d_wkT, void* d_qt, int32_t n);
+
+/* Decode-step HIP graphs this engine holds (test hook: the count must stay bounded whatever row counts callers submit). */
+int mocr_graph_count(mocr_engine* e);
+/* Free / total bytes of HBM on a device (the Python constructor sizes its default max_batch from it). */
+int mocr_device_memory(int32_t device, int64_t* free_bytes, int64_t* total_bytes);
 
 /* ---- per-kernel timing (HIP events on the engine's stream) -------------------------------- */
 typedef struct mocr_kernel_stat {

@@ -119,6 +119,7 @@ struct Lane {
     bool active = false;
     std::vector<Job> jobs;          // requests merged into this lane's current batch, in row order
     int n = 0, max_len = 0;         // rows of the merged batch, its generate(max_length)
+    int np = 0;                     // rows the decode steps run on: n rounded up (graph_rows), the extra rows are born finished
     int t = 0, steps = 0, chunk = 0;
     bool flag_pending[2] = {false, false};
     hipEvent_t flag_ev[2] = {nullptr, nullptr};
@@ -128,6 +129,8 @@ struct mocr_engine : LaneCtx {
     mocr_config cfg{};
     std::string err;
     std::mutex mu;
+    std::mutex err_mu;              // guards err: mocr_last_error may be called while another thread fails
+    bool poisoned = false;          // a HIP call failed: HIP errors are sticky, so every later call is refused
     bool committed = false;
     bool latent = false;            // bf16 engines: latent (absorbed) decode attention ...
     int classic_rows = 0;           // ... for batches of more than this many rows; smaller ones use the classic kernels
@@ -473,8 +476,9 @@ void dec_add_ln(mocr_engine* e, int nslab, int N, const float* bias, const float
     HIPCHECK(hipGetLastError());
 }
 
-static DecState make_state(mocr_engine* e, int max_len, const int* forced, int forced_T, float* logits_out) {
+static DecState make_state(mocr_engine* e, int max_len, const int* forced, int forced_T, float* logits_out, int n_real) {
     DecState st{};
+    st.n_real = n_real;
     st.ids = e->ids; st.step = e->step; st.finished = e->finished; st.len = e->len; st.n_unfinished = e->n_unf;
     st.forced = forced; st.forced_T = forced_T; st.logits_out = logits_out;
     st.ids_ld = e->cfg.max_len; st.max_len = max_len;
@@ -728,7 +732,7 @@ hipGraphExec_t decode_graph(mocr_engine* e, const DecState& st, int n, int steps
 // Teacher-forced decode (test hook): eager launches, logits of every step kept.
 template <typename T>
 void run_decode_forced(mocr_engine* e, int n, const int* forced, int forced_T, float* logits_out) {
-    DecState st = make_state(e, e->cfg.max_len, forced, forced_T, logits_out);
+    DecState st = make_state(e, e->cfg.max_len, forced, forced_T, logits_out, n);
     dec_token<T, true>(e, st, 0, n);
     for (int t = 0; t < forced_T; ++t) decode_step<T>(e, st, n, t);
 }
@@ -740,6 +744,20 @@ void run_decode_forced(mocr_engine* e, int n, const int* forced, int forced_T, f
 // before chunk c is enqueued, so a lane always has work queued while the host looks at a flag, and
 // a batch whose rows have all emitted EOS stops at most one chunk late.
 constexpr int CHUNK = 8;
+
+// Decode graphs are keyed by row count.  Callers submit any n in 1..max_batch (the batcher of MangaOcr, the crop-job
+// queue), so n is rounded up to a coarse grid before it becomes a key: at most ~40 distinct row counts per engine
+// instead of max_batch, i.e. a bounded number of captures / instantiated graphs, and a batch of 37 crops replays the
+// graph a batch of 40 captured.  The padding costs <= 12.5 % more rows in the (latency-bound) decode steps.
+static int graph_rows(int n, int max_batch) {
+    int q;
+    if (n <= 8) q = 1;
+    else if (n <= 64) q = 8;
+    else if (n <= 256) q = 32;
+    else if (n <= 1024) q = 128;
+    else q = 512;
+    return std::min(round_up(n, q), max_batch);
+}
 
 template <typename T>
 void start_batch(mocr_engine* e, Lane& L) {
@@ -769,11 +787,13 @@ void start_batch(mocr_engine* e, Lane& L) {
         row0 += j.n;
     }
     run_encoder<T>(e, e->d_in, L.n);
-    if (!e->use_latent(L.n)) run_cross_kv<T>(e, L.n);
+    if (!e->use_latent(L.np)) run_cross_kv<T>(e, L.n);
     // rows read pad_id (= 0) beyond what the loop writes
-    HIPCHECK(hipMemsetAsync(e->ids, 0, (size_t)L.n * e->cfg.max_len * sizeof(int), e->stream));
-    DecState st = make_state(e, L.max_len, nullptr, 0, nullptr);
-    dec_token<T, true>(e, st, 0, L.n);
+    HIPCHECK(hipMemsetAsync(e->ids, 0, (size_t)L.np * e->cfg.max_len * sizeof(int), e->stream));
+    // The decode steps run on np >= n rows (graph_rows): the padding rows are born finished, emit pad_id and read
+    // whatever the workspace holds for them (finite values; no kernel mixes rows).
+    DecState st = make_state(e, L.max_len, nullptr, 0, nullptr, L.n);
+    dec_token<T, true>(e, st, 0, L.np);
     L.t = 0; L.steps = L.max_len - 1; L.chunk = 0;
     L.flag_pending[0] = L.flag_pending[1] = false;
 }
@@ -801,15 +821,15 @@ void advance(mocr_engine* e, Lane& L) {
         if (e->h_pinned[slot] <= 0) { finish_batch(e, L); return; }
     }
     if (L.t >= L.steps) { finish_batch(e, L); return; }
-    DecState st = make_state(e, L.max_len, nullptr, 0, nullptr);
+    DecState st = make_state(e, L.max_len, nullptr, 0, nullptr, L.n);
     const int k = std::min(CHUNK, L.steps - L.t);
     const bool use_graph = !e->prof_on && !(e->cfg.flags & MOCR_FLAG_NO_GRAPH);
     if (use_graph && k == CHUNK) {
-        HIPCHECK(hipGraphLaunch(decode_graph<T>(e, st, L.n, CHUNK, L.t), e->stream));
+        HIPCHECK(hipGraphLaunch(decode_graph<T>(e, st, L.np, CHUNK, L.t), e->stream));
     } else {
         for (int i = 0; i < k; ++i) {
-            if (use_graph) HIPCHECK(hipGraphLaunch(decode_graph<T>(e, st, L.n, 1, L.t + i), e->stream));
-            else decode_step<T>(e, st, L.n, L.t + i);
+            if (use_graph) HIPCHECK(hipGraphLaunch(decode_graph<T>(e, st, L.np, 1, L.t + i), e->stream));
+            else decode_step<T>(e, st, L.np, L.t + i);
         }
     }
     L.t += k;
@@ -840,6 +860,7 @@ bool pump_once(mocr_engine* e) {
                 ++take;
             }
             e->pending.erase(e->pending.begin(), e->pending.begin() + take);
+            L.np = graph_rows(L.n, e->cfg.max_batch);
             L.active = true;
             e->bind((int)i);
             start_batch<T>(e, L);
@@ -1054,7 +1075,7 @@ void allocate_lane(mocr_engine* e, int lane_id) {
     e->CTX = e->dalloc<char>(Mp * D * esz);
     e->Hb = e->dalloc<char>(Mp * (size_t)e->F * esz);
     e->ENC = e->dalloc<char>(Mp * D * esz);
-    if (e->latent) {
+    if (e->latent && e->classic_rows < c.max_batch) {      // else every batch takes the classic kernels
         e->q_t = e->dalloc<char>(Bp * D * esz);
         e->qt = e->dalloc<char>(Bp * 16 * D * esz);
         e->et = e->dalloc<char>(Bp * 16 * D * esz);
@@ -1098,24 +1119,36 @@ void allocate_lanes(mocr_engine* e) {
     e->bind(0);
 }
 
+static void set_error(mocr_engine* e, const std::string& msg) {
+    std::lock_guard<std::mutex> lk(e->err_mu);
+    e->err = msg;
+}
+
 template <typename F> int guarded(mocr_engine* e, F&& f) {
     if (!e) return MOCR_ERR_ARG;
+    if (e->poisoned) {
+        // after a failed HIP call (a fault, a lost device) the context is not trustworthy and HIP keeps
+        // returning the same error: refuse instead of serving from a half-dead engine
+        return MOCR_ERR_STATE;
+    }
     try {
         f();
         return MOCR_OK;
     } catch (const HipError& h) {
         char buf[512];
-        snprintf(buf, sizeof(buf), "HIP error %d (%s) at engine.hip:%d: %s", (int)h.code, hipGetErrorString(h.code), h.line, h.what);
-        e->err = buf;
+        snprintf(buf, sizeof(buf), "HIP error %d (%s) at engine.hip:%d: %s - the engine refuses further calls (MOCR_ERR_STATE) until it is destroyed",
+                 (int)h.code, hipGetErrorString(h.code), h.line, h.what);
+        set_error(e, buf);
+        e->poisoned = true;
         return MOCR_ERR_HIP;
     } catch (const ArgError& a) {
-        e->err = a.msg;
+        set_error(e, a.msg);
         return a.code;
     } catch (const std::bad_alloc&) {
-        e->err = "host allocation failed";
+        set_error(e, "host allocation failed");
         return MOCR_ERR_NOMEM;
     } catch (const std::exception& x) {
-        e->err = x.what();
+        set_error(e, x.what());
         return MOCR_ERR_STATE;
     }
 }
@@ -1162,7 +1195,7 @@ int mocr_create(const mocr_config* cfg, mocr_engine** out) {
         allocate_lanes(e);
     });
     if (rc != MOCR_OK) {
-        fprintf(stderr, "mocr_create failed: %s\n", e->err.c_str());
+        fprintf(stderr, "mocr_create failed: %s\n", mocr_last_error(e));
         mocr_destroy(e);
         return rc;
     }
@@ -1189,7 +1222,16 @@ void mocr_destroy(mocr_engine* e) {
     delete e;
 }
 
-const char* mocr_last_error(const mocr_engine* e) { return e ? e->err.c_str() : "null engine"; }
+const char* mocr_last_error(const mocr_engine* e) {
+    if (!e) return "null engine";
+    // a copy taken under the error mutex, owned by the calling thread: valid until that thread's next call of this
+    // function, whatever other threads do to the engine meanwhile
+    static thread_local std::string copy;
+    mocr_engine* m = const_cast<mocr_engine*>(e);
+    std::lock_guard<std::mutex> lk(m->err_mu);
+    copy = m->err;
+    return copy.c_str();
+}
 
 int mocr_set_tensor(mocr_engine* e, const char* name, const float* data, const int64_t* shape, int32_t ndim) {
     return guarded(e, [&] {
@@ -1276,18 +1318,33 @@ int mocr_recognize_gray_host(mocr_engine* e, const uint8_t* gray, int32_t n, int
     });
 }
 
-// L conversion + Pillow-exact BILINEAR resize of n host images (any sizes) into d_out [n][IMG][IMG] u8 on the
-// device; synchronous (lane 0's stream).
-static void preprocess_images(mocr_engine* e, const mocr_image* imgs, int n, uint8_t* d_out) {
+// Host pixels uploaded once (an image, or a whole page several crops are cut from) ...
+struct PrepSource { const uint8_t* data; int h, w; int64_t row_stride; int ch; int bgr; };
+// ... and what one crop reads of its source: the rectangle [x, x+w) x [y, y+h)
+struct PrepView { int source, x, y, w, h; };
+
+static PrepSource source_of(const mocr_image& im) {
+    const int ch = im.channels == MOCR_CHANNELS_BGR ? 3 : im.channels;
+    if (!im.data || im.height < 1 || im.width < 1 || im.height > 16384 || im.width > 16384 || (ch != 1 && ch != 3) ||
+        im.row_stride < (int64_t)im.width * ch)
+        throw ArgError{"bad image descriptor (channels must be 1 = L, 3 = RGB or MOCR_CHANNELS_BGR)", MOCR_ERR_ARG};
+    return PrepSource{im.data, im.height, im.width, im.row_stride, ch, im.channels == MOCR_CHANNELS_BGR ? 1 : 0};
+}
+
+// L conversion + Pillow-exact BILINEAR resize of the views (any sizes) into d_out [views][IMG][IMG] u8 on the
+// device; synchronous (lane 0's stream).  Every source is uploaded once, however many views read it: the crops of
+// a page's detected regions are cut ON THE DEVICE (descriptor = offset + page stride), not copied out on the host.
+static void preprocess_views(mocr_engine* e, const std::vector<PrepSource>& srcs, const PrepView* views, int n, uint8_t* d_out) {
     const int IMG = e->cfg.image_size;
     if (n > 4096) {          // bounded scratch and grid.y: 4096 crops per pass
-        for (int b = 0; b < n; b += 4096) preprocess_images(e, imgs + b, std::min(4096, n - b), d_out + (size_t)b * IMG * IMG);
+        for (int b = 0; b < n; b += 4096) preprocess_views(e, srcs, views + b, std::min(4096, n - b), d_out + (size_t)b * IMG * IMG);
         return;
     }
     if (IMG != 224) throw ArgError{"device preprocessing is instantiated for image_size 224", MOCR_ERR_UNSUPPORTED};
     std::vector<ResizeDesc> descs(n);
     std::vector<int> coef, bounds;
     std::map<int, std::pair<int, int>> placed;        // input size -> (coef offset, bounds offset) in this call's buffers
+    std::map<int, long long> src_off;                 // sources this pass reads -> byte offset in the packed upload
     size_t src_bytes = 0, tmp_bytes = 0;
     int max_h = 0;
     auto place = [&](int in_size, int& k_off, int& b_off, int& ks) {
@@ -1304,25 +1361,34 @@ static void preprocess_images(mocr_engine* e, const mocr_image* imgs, int n, uin
         k_off = pl->second.first; b_off = pl->second.second; ks = t.ksize;
     };
     for (int i = 0; i < n; ++i) {
-        const mocr_image& im = imgs[i];
-        if (!im.data || im.height < 1 || im.width < 1 || im.height > 16384 || im.width > 16384 || (im.channels != 1 && im.channels != 3) ||
-            im.row_stride < (int64_t)im.width * im.channels)
-            throw ArgError{"bad image descriptor (channels must be 1 = L or 3 = RGB)", MOCR_ERR_ARG};
+        const PrepView& v = views[i];
+        if (v.source < 0 || v.source >= (int)srcs.size()) throw ArgError{"view of an unknown source", MOCR_ERR_ARG};
+        const PrepSource& sc = srcs[v.source];
+        if (v.w < 1 || v.h < 1 || v.x < 0 || v.y < 0 || v.x + v.w > sc.w || v.y + v.h > sc.h)
+            throw ArgError{"view outside its source image", MOCR_ERR_ARG};
+        auto so = src_off.find(v.source);
+        if (so == src_off.end()) {
+            so = src_off.emplace(v.source, (long long)src_bytes).first;
+            src_bytes += (size_t)sc.h * sc.w * sc.ch;
+        }
         ResizeDesc& d = descs[i];
-        d.h = im.height; d.w = im.width; d.channels = im.channels; d.stride = im.width * im.channels;
-        d.src_off = (long long)src_bytes; d.tmp_off = (long long)tmp_bytes;
-        src_bytes += (size_t)d.h * d.stride;
+        d.h = v.h; d.w = v.w; d.channels = sc.ch; d.bgr = sc.bgr; d.stride = sc.w * sc.ch;
+        d.src_off = so->second + ((long long)v.y * sc.w + v.x) * sc.ch;
+        d.tmp_off = (long long)tmp_bytes;
         tmp_bytes += (size_t)d.h * IMG;
         place(d.w, d.kx_off, d.bx_off, d.ksx);
         place(d.h, d.ky_off, d.by_off, d.ksy);
         max_h = std::max(max_h, d.h);
     }
-    // pack the pixel rows (drops the callers' row padding), one copy per buffer
+    // pack the pixel rows of every source (drops the callers' row padding), one copy per buffer
     std::vector<uint8_t> packed(src_bytes);
-    for (int i = 0; i < n; ++i)
-        for (int y = 0; y < descs[i].h; ++y)
-            memcpy(packed.data() + descs[i].src_off + (size_t)y * descs[i].stride, imgs[i].data + (size_t)y * imgs[i].row_stride,
-                   (size_t)descs[i].stride);
+    for (const auto& so : src_off) {
+        const PrepSource& sc = srcs[so.first];
+        const size_t rowb = (size_t)sc.w * sc.ch;
+        if ((int64_t)rowb == sc.row_stride) memcpy(packed.data() + so.second, sc.data, rowb * sc.h);
+        else
+            for (int y = 0; y < sc.h; ++y) memcpy(packed.data() + so.second + (size_t)y * rowb, sc.data + (size_t)y * sc.row_stride, rowb);
+    }
     uint8_t* d_src = (uint8_t*)e->grow(e->rs_src, src_bytes);
     uint8_t* d_tmp = (uint8_t*)e->grow(e->rs_tmp, tmp_bytes);
     ResizeDesc* d_desc = (ResizeDesc*)e->grow(e->rs_desc, descs.size() * sizeof(ResizeDesc));
@@ -1345,6 +1411,30 @@ static void preprocess_images(mocr_engine* e, const mocr_image* imgs, int n, uin
         HIPCHECK(hipGetLastError());
     }
     HIPCHECK(hipStreamSynchronize(e->stream));       // `packed` and the descriptors are host temporaries
+}
+
+static void preprocess_images(mocr_engine* e, const mocr_image* imgs, int n, uint8_t* d_out) {
+    std::vector<PrepSource> srcs(n);
+    std::vector<PrepView> views(n);
+    for (int i = 0; i < n; ++i) {
+        srcs[i] = source_of(imgs[i]);
+        views[i] = PrepView{i, 0, 0, srcs[i].w, srcs[i].h};
+    }
+    preprocess_views(e, srcs, views.data(), n, d_out);
+}
+
+// Decode device-resident luminance planes d_gray [n][IMG][IMG] into host outputs, in max_batch-row jobs.
+static void recognize_planes(mocr_engine* e, const uint8_t* d_gray, int n, int32_t* out_ids, int32_t* out_len) {
+    const size_t plane = (size_t)e->cfg.image_size * e->cfg.image_size;
+    for (int base = 0; base < n; base += e->cfg.max_batch) {
+        Job j;
+        j.src = d_gray + (size_t)base * plane; j.src_host = false; j.channels = 1;
+        j.row_stride = e->cfg.image_size; j.image_stride = (int64_t)plane;
+        j.n = std::min(e->cfg.max_batch, n - base); j.max_len = e->cfg.max_len;
+        j.out_ids = out_ids + (size_t)base * e->cfg.max_len; j.out_len = out_len + base; j.out_host = true;
+        e->pending.push_back(j);
+    }
+    drive(e);
 }
 
 int mocr_preprocess(mocr_engine* e, const mocr_image* images, int32_t n, uint8_t* out_gray) {
@@ -1374,16 +1464,82 @@ int mocr_recognize_images(mocr_engine* e, const mocr_image* images, int32_t n, i
         uint8_t* d_gray = (uint8_t*)e->grow(e->rs_gray, (size_t)n * plane);
         preprocess_images(e, images, n, d_gray);
         e->unbind(0);
-        for (int base = 0; base < n; base += e->cfg.max_batch) {
-            Job j;
-            j.src = d_gray + (size_t)base * plane; j.src_host = false; j.channels = 1;
-            j.row_stride = e->cfg.image_size; j.image_stride = (int64_t)plane;
-            j.n = std::min(e->cfg.max_batch, n - base); j.max_len = e->cfg.max_len;
-            j.out_ids = out_ids + (size_t)base * e->cfg.max_len; j.out_len = out_len + base; j.out_host = true;
-            e->pending.push_back(j);
-        }
-        drive(e);
+        recognize_planes(e, d_gray, n, out_ids, out_len);
     });
+}
+
+// The crop a detected text region gets (src/ui/main_window.py:9530-9540): its bounding box grown by
+// int(max(w, h) * 0.08) on every side, clipped to the page; false when no more than a 1-pixel sliver is left
+// (the reference then returns '' without calling the recogniser).
+static bool padded_region(const mocr_region& r, int page_h, int page_w, PrepView& v) {
+    if (r.width < 0 || r.height < 0) throw ArgError{"region with a negative size", MOCR_ERR_ARG};
+    const int pad = (int)((double)std::max(r.width, r.height) * 0.08);
+    const long long x1 = std::max<long long>((long long)r.x - pad, 0), y1 = std::max<long long>((long long)r.y - pad, 0);
+    const long long x2 = std::min<long long>((long long)r.x + r.width + pad, page_w), y2 = std::min<long long>((long long)r.y + r.height + pad, page_h);
+    if (x2 - x1 <= 1 || y2 - y1 <= 1) return false;
+    v.x = (int)x1; v.y = (int)y1; v.w = (int)(x2 - x1); v.h = (int)(y2 - y1);
+    return true;
+}
+
+int mocr_recognize_regions(mocr_engine* e, const mocr_image* pages, int32_t n_pages, const mocr_region* regions, int32_t n_regions,
+                           int32_t* out_ids, int32_t* out_len) {
+    return guarded(e, [&] {
+        std::lock_guard<std::mutex> lk(e->mu);
+        if (!e->committed) throw ArgError{"weights not committed (mocr_commit_weights)", MOCR_ERR_STATE};
+        if (!pages || n_pages < 1 || n_regions < 0 || (n_regions > 0 && (!regions || !out_ids || !out_len)))
+            throw ArgError{"bad argument", MOCR_ERR_ARG};
+        if (n_regions == 0) return;
+        HIPCHECK(hipSetDevice(e->cfg.device));
+        drive(e);
+        std::vector<PrepSource> srcs(n_pages);
+        for (int i = 0; i < n_pages; ++i) srcs[i] = source_of(pages[i]);
+        std::vector<PrepView> views;
+        std::vector<int> where(n_regions, -1);          // region -> its row among the recognised crops (-1: sliver)
+        for (int i = 0; i < n_regions; ++i) {
+            const mocr_region& r = regions[i];
+            if (r.page < 0 || r.page >= n_pages) throw ArgError{"region of an unknown page", MOCR_ERR_ARG};
+            PrepView v{r.page, 0, 0, 0, 0};
+            if (!padded_region(r, srcs[r.page].h, srcs[r.page].w, v)) continue;
+            where[i] = (int)views.size();
+            views.push_back(v);
+        }
+        const int L = e->cfg.max_len, nv = (int)views.size();
+        std::vector<int32_t> ids((size_t)nv * L), lens(nv);
+        if (nv > 0) {
+            const size_t plane = (size_t)e->cfg.image_size * e->cfg.image_size;
+            e->bind(0);
+            uint8_t* d_gray = (uint8_t*)e->grow(e->rs_gray, (size_t)nv * plane);
+            preprocess_views(e, srcs, views.data(), nv, d_gray);
+            e->unbind(0);
+            recognize_planes(e, d_gray, nv, ids.data(), lens.data());
+        }
+        for (int i = 0; i < n_regions; ++i) {
+            int32_t* row = out_ids + (size_t)i * L;
+            if (where[i] < 0) {
+                for (int t = 0; t < L; ++t) row[t] = e->cfg.pad_id;
+                out_len[i] = 0;
+            } else {
+                memcpy(row, ids.data() + (size_t)where[i] * L, (size_t)L * sizeof(int32_t));
+                out_len[i] = lens[where[i]];
+            }
+        }
+    });
+}
+
+int mocr_graph_count(mocr_engine* e) {
+    if (!e) return MOCR_ERR_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    return (int)e->graphs.size();
+}
+
+int mocr_device_memory(int32_t device, int64_t* free_bytes, int64_t* total_bytes) {
+    if (!free_bytes || !total_bytes) return MOCR_ERR_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return MOCR_ERR_HIP;
+    size_t f = 0, t = 0;
+    if (hipSetDevice(device) != hipSuccess || hipMemGetInfo(&f, &t) != hipSuccess) return MOCR_ERR_HIP;
+    *free_bytes = (int64_t)f; *total_bytes = (int64_t)t;
+    return MOCR_OK;
 }
 
 int mocr_encode(mocr_engine* e, const void* d_gray, int32_t n, float* h_out) {

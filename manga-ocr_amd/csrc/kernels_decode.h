@@ -108,6 +108,7 @@ struct DecState {
     int ids_ld;        // row stride of ids
     int max_len;       // generate(max_length): a row is finished when it holds max_len tokens
     int start_id, eos_id, pad_id;
+    int n_real;        // rows >= n_real are padding (the batch is rounded up to a graph-friendly row count): born finished
 };
 
 // End of a decode step, one block per sequence:
@@ -134,9 +135,9 @@ __global__ __launch_bounds__(256) void dec_token_kernel(const float* __restrict_
     if (FIRST) {
         if (tid == 0) {
             st.ids[(size_t)b * st.ids_ld] = st.start_id;
-            st.step[b] = 0; st.finished[b] = 0; st.len[b] = st.max_len;
+            st.step[b] = 0; st.finished[b] = b >= st.n_real ? 1 : 0; st.len[b] = st.max_len;
             s_tok = st.start_id; s_pos = 0;
-            if (b == 0) *st.n_unfinished = (int)gridDim.x;
+            if (b == 0) *st.n_unfinished = st.n_real;
         }
     } else {
         const int t = st.step[b];
@@ -184,6 +185,7 @@ __global__ __launch_bounds__(256) void dec_token_kernel(const float* __restrict_
         if (tid == 0) {
             for (int w = 1; w < 4; ++w)
                 if (s_val[w] > best || (s_val[w] == best && s_idx[w] < bi)) { best = s_val[w]; bi = s_idx[w]; }
+            if ((unsigned)bi >= (unsigned)V) bi = 0;      // all-NaN logits win no comparison: stay inside the embedding table
             int fin = st.finished[b];
             int tok = fin ? st.pad_id : bi;
             if (st.forced) tok = (t + 1 < st.forced_T) ? st.forced[(size_t)b * st.forced_T + t + 1] : st.pad_id;

@@ -75,13 +75,17 @@ struct ResizeDesc {
     long long src_off;     // byte offset of the image in the packed source buffer
     long long tmp_off;     // byte offset of its [h][OUT] horizontal-pass plane
     int h, w, stride, channels;
+    int bgr;               // 3-channel pixels are stored B,G,R (OpenCV order, what the reference's crop tools hold)
     int kx_off, bx_off, ksx;   // int offsets into the coefficient / bounds buffers, taps per output (0: pass skipped)
     int ky_off, by_off, ksy;
 };
 
-__device__ __forceinline__ int rs_luma(const uint8_t* p, int channels) {
+__device__ __forceinline__ int rs_luma(const uint8_t* p, int channels, int bgr) {
     if (channels == 1) return p[0];
-    return (int)((19595u * p[0] + 38470u * p[1] + 7471u * p[2] + 0x8000u) >> 16);
+    // BGR input: the reference converts BGR -> RGB on the host first (src/ui/main_window.py:9800, cv2.COLOR_BGR2RGB),
+    // a pure channel swap, so reading the channels in the other order is the same arithmetic
+    const unsigned r = bgr ? p[2] : p[0], b = bgr ? p[0] : p[2];
+    return (int)((19595u * r + 38470u * p[1] + 7471u * b + 0x8000u) >> 16);
 }
 __device__ __forceinline__ uint8_t rs_clip8(int v) {
     v >>= MOCR_RS_PRECISION_BITS;              // arithmetic shift, like clip8_lookups[in >> PRECISION_BITS]
@@ -110,10 +114,10 @@ __global__ __launch_bounds__(256) void resize_h_kernel(const uint8_t* __restrict
         const uint8_t* row = src + d.src_off + (size_t)y * d.stride;
         uint8_t o;
         if (!d.ksx) {                        // width already OUT: Pillow skips the pass
-            o = (uint8_t)rs_luma(row + (size_t)xx * d.channels, d.channels);
+            o = (uint8_t)rs_luma(row + (size_t)xx * d.channels, d.channels, d.bgr);
         } else {
             int acc = 1 << (MOCR_RS_PRECISION_BITS - 1);
-            for (int x = 0; x < cnt; ++x) acc += rs_luma(row + (size_t)(xmin + x) * d.channels, d.channels) * k[x];
+            for (int x = 0; x < cnt; ++x) acc += rs_luma(row + (size_t)(xmin + x) * d.channels, d.channels, d.bgr) * k[x];
             o = rs_clip8(acc);
         }
         tmp[d.tmp_off + (size_t)y * OUT + xx] = o;

@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "_lib", "libmocr_hip.so")
 MOCR_OK = 0
 MOCR_F32, MOCR_BF16 = 0, 1
 FLAG_SIMPLE_ATTENTION, FLAG_NO_GRAPH, FLAG_NO_EARLY_EXIT, FLAG_CLASSIC_ATTENTION = 1, 2, 4, 8
+FLAG_NO_FUSED_ARGMAX, FLAG_NO_FUSED_QQT, FLAG_LATENT_ALWAYS = 16, 32, 64
 EPI_SLAB, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_PATCH, EPI_BIAS_F32 = range(6)
 
 
@@ -35,6 +36,13 @@ class MocrImage(C.Structure):
                 ("channels", C.c_int32)]
 
 
+class MocrRegion(C.Structure):
+    """include/mocr.h: mocr_region"""
+    _fields_ = [(n, C.c_int32) for n in ("page", "x", "y", "width", "height")]
+
+
+CHANNELS_BGR = -3
+
 SYMBOLS = {
     "mocr_abi_version": (C.c_int, []),
     "mocr_create": (C.c_int, [C.POINTER(MocrConfig), C.POINTER(_P)]),
@@ -44,6 +52,9 @@ SYMBOLS = {
     "mocr_commit_weights": (C.c_int, [_P]),
     "mocr_recognize": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int32, _P, _P]),
     "mocr_recognize_images": (C.c_int, [_P, C.POINTER(MocrImage), C.c_int32, _P, _P]),
+    "mocr_recognize_regions": (C.c_int, [_P, C.POINTER(MocrImage), C.c_int32, C.POINTER(MocrRegion), C.c_int32, _P, _P]),
+    "mocr_graph_count": (C.c_int, [_P]),
+    "mocr_device_memory": (C.c_int, [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "mocr_preprocess": (C.c_int, [_P, C.POINTER(MocrImage), C.c_int32, _P]),
     "mocr_recognize_device": (C.c_int, [_P, _P, C.c_int32, _P, _P]),
     "mocr_synchronize": (C.c_int, [_P]),

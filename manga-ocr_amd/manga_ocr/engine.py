@@ -26,6 +26,16 @@ def _ptr(a) -> C.c_void_p:
     raise TypeError(f"cannot take the address of {type(a)}")
 
 
+def device_memory(device: int = 0) -> Tuple[int, int]:
+    """(free, total) bytes of HBM on a device."""
+    lib = _capi.load_library()
+    f, t = C.c_int64(0), C.c_int64(0)
+    rc = lib.mocr_device_memory(device, C.byref(f), C.byref(t))
+    if rc != _capi.MOCR_OK:
+        raise _capi.MocrError(f"mocr_device_memory({device}) failed with code {rc} (is a MI355X visible to this process?)")
+    return int(f.value), int(t.value)
+
+
 class Engine:
     """One engine = one GPU = one HIP stream.  Thread-safe (calls are serialised natively)."""
 
@@ -96,38 +106,67 @@ class Engine:
         self._check(self.lib.mocr_recognize(self._h, _ptr(a), n, h, w, w * ch, h * w * ch, ch, _ptr(ids), _ptr(lens)))
         return ids, lens
 
-    def _image_descs(self, images):
-        """numpy uint8 [h,w] (L) or [h,w,3] (RGB) arrays of any sizes -> (ctypes array of mocr_image, keep-alive list)."""
+    def _image_descs(self, images, bgr: bool = False):
+        """numpy uint8 [h,w] (L) or [h,w,3] (RGB; B,G,R order when `bgr`) arrays of any sizes -> (ctypes array of
+        mocr_image, keep-alive list).  Arrays with contiguous pixels and any row stride are passed as they are
+        (a crop that is a view into a page is not copied here)."""
         keep = []
         descs = (_capi.MocrImage * len(images))()
         for i, im in enumerate(images):
-            a = np.ascontiguousarray(im, dtype=np.uint8)
+            a = im if isinstance(im, np.ndarray) and im.dtype == np.uint8 else np.ascontiguousarray(im, dtype=np.uint8)
             if a.ndim == 2:
                 ch = 1
             elif a.ndim == 3 and a.shape[2] == 3:
                 ch = 3
             else:
                 raise ValueError("each image must be uint8 [h,w] or [h,w,3]")
+            pix_ok = a.strides[1] == ch and (ch == 1 or a.strides[2] == 1) and a.strides[0] >= a.shape[1] * ch
+            if not pix_ok:
+                a = np.ascontiguousarray(a)
             keep.append(a)
             descs[i].data = a.ctypes.data
             descs[i].height, descs[i].width = a.shape[0], a.shape[1]
-            descs[i].row_stride = a.shape[1] * ch
-            descs[i].channels = ch
+            descs[i].row_stride = a.strides[0]
+            descs[i].channels = _capi.CHANNELS_BGR if (bgr and ch == 3) else ch
         return descs, keep
 
-    def recognize_images(self, images) -> Tuple[np.ndarray, np.ndarray]:
-        """Crops of any sizes (list of uint8 [h,w] / [h,w,3] arrays): luminance conversion and the Pillow-exact
-        BILINEAR resize to 224x224 run on the device.  Returns (ids int32 [n,max_len], lengths int32 [n])."""
-        descs, keep = self._image_descs(images)
+    def recognize_images(self, images, bgr: bool = False) -> Tuple[np.ndarray, np.ndarray]:
+        """Crops of any sizes (list of uint8 [h,w] / [h,w,3] arrays; `bgr`: 3-channel crops are in OpenCV order):
+        luminance conversion and the Pillow-exact BILINEAR resize to 224x224 run on the device.
+        Returns (ids int32 [n,max_len], lengths int32 [n])."""
+        if len(images) == 0:
+            return np.zeros((0, self.spec.max_len), dtype=np.int32), np.zeros(0, dtype=np.int32)
+        descs, keep = self._image_descs(images, bgr)
         n = len(keep)
         ids = np.zeros((n, self.spec.max_len), dtype=np.int32)
         lens = np.zeros(n, dtype=np.int32)
         self._check(self.lib.mocr_recognize_images(self._h, descs, n, _ptr(ids), _ptr(lens)))
         return ids, lens
 
-    def preprocess(self, images) -> np.ndarray:
+    def recognize_regions(self, pages, regions, bgr: bool = True) -> Tuple[np.ndarray, np.ndarray]:
+        """pages: list of uint8 [H,W,3] (or [H,W]) arrays; regions: iterable of (page_index, x, y, w, h) bounding
+        rectangles.  Each page is uploaded once; the 8 %-padded, page-clipped crop of every region
+        (``src/ui/main_window.py:9530-9540``) is cut on the device.  Returns (ids [n,max_len], lengths [n]);
+        a region reduced to a sliver has length 0."""
+        regs = list(regions)
+        n = len(regs)
+        ids = np.zeros((n, self.spec.max_len), dtype=np.int32)
+        lens = np.zeros(n, dtype=np.int32)
+        if n == 0:
+            return ids, lens
+        descs, keep = self._image_descs(pages, bgr)
+        arr = (_capi.MocrRegion * n)()
+        for i, (pg, x, y, w, h) in enumerate(regs):
+            arr[i].page, arr[i].x, arr[i].y, arr[i].width, arr[i].height = int(pg), int(x), int(y), int(w), int(h)
+        self._check(self.lib.mocr_recognize_regions(self._h, descs, len(keep), arr, n, _ptr(ids), _ptr(lens)))
+        return ids, lens
+
+    def graph_count(self) -> int:
+        return int(self.lib.mocr_graph_count(self._h))
+
+    def preprocess(self, images, bgr: bool = False) -> np.ndarray:
         """Test hook: the uint8 [n,224,224] planes the encoder sees for these crops."""
-        descs, keep = self._image_descs(images)
+        descs, keep = self._image_descs(images, bgr)
         out = np.zeros((len(keep), self.spec.image_size, self.spec.image_size), dtype=np.uint8)
         self._check(self.lib.mocr_preprocess(self._h, descs, len(keep), _ptr(out)))
         return out

@@ -18,9 +18,11 @@ from typing import Iterable, List, Optional, Sequence
 
 SPECIAL_TOKENS = ("[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]")
 
-_HALF_ASCII = "!\"#$%&'()*+,-./:;<=>?@[\\]^_`~ " + "abcdefghijklmnopqrstuvwxyz" + "ABCDEFGHIJKLMNOPQRSTUVWXYZ" + "{|}"
-_FULL_ASCII = "！＂＃＄％＆＇（）＊＋，－．／：；＜＝＞？＠［＼］＾＿｀～　" + "ａｂｃｄｅｆｇｈｉｊｋｌｍｎｏｐｑｒｓｔｕｖｗｘｙｚ" + \
-              "ＡＢＣＤＥＦＧＨＩＪＫＬＭＮＯＰＱＲＳＴＵＶＷＸＹＺ" + "｛｜｝"
+# jaconv's conv_table [RECALL, two independent recollections agree; the package is not installed here]: the
+# full-width partners of " ' \ ` are the typographic ” ’ ￥ ‘, not the code-point-shifted ＂ ＇ ＼ ｀.
+_HALF_ASCII = "abcdefghijklmnopqrstuvwxyz" + "ABCDEFGHIJKLMNOPQRSTUVWXYZ" + "!\"#$%&'()*+,-./:;<=>?@[\\]^_`{|}~ "
+_FULL_ASCII = "ａｂｃｄｅｆｇｈｉｊｋｌｍｎｏｐｑｒｓｔｕｖｗｘｙｚ" + "ＡＢＣＤＥＦＧＨＩＪＫＬＭＮＯＰＱＲＳＴＵＶＷＸＹＺ" + \
+              "！”＃＄％＆’（）＊＋，－．／：；＜＝＞？＠［￥］＾＿‘｛｜｝～　"
 _HALF_DIGIT = "0123456789"
 _FULL_DIGIT = "０１２３４５６７８９"
 _HALF_KANA = "ｧｱｨｲｩｳｪｴｫｵｶｷｸｹｺｻｼｽｾｿﾀﾁｯﾂﾃﾄﾅﾆﾇﾈﾉﾊﾋﾌﾍﾎﾏﾐﾑﾒﾓｬﾔｭﾕｮﾖﾗﾘﾙﾚﾛﾜｦﾝｰ｡｢｣､･ﾞﾟ"
@@ -37,29 +39,40 @@ _H2Z_V = {h + "ﾞ": f for h, f in zip(_VOICED_HALF, _VOICED_FULL)}
 _H2Z_S = {h + "ﾟ": f for h, f in zip(_SEMI_HALF, _SEMI_FULL)}
 
 
+_H2Z_TR = {(True, False, False): str.maketrans(_H2Z_K),
+           (True, True, False): str.maketrans({**_H2Z_K, **_H2Z_A}),
+           (True, False, True): str.maketrans({**_H2Z_K, **_H2Z_D}),
+           (True, True, True): str.maketrans({**_H2Z_K, **_H2Z_A, **_H2Z_D}),
+           (False, True, False): str.maketrans(_H2Z_A),
+           (False, False, True): str.maketrans(_H2Z_D),
+           (False, True, True): str.maketrans({**_H2Z_A, **_H2Z_D}),
+           (False, False, False): {}}
+
+
+def _h2z_tables(text: str, kana: bool = True, ascii: bool = False, digit: bool = False) -> str:
+    """The restated tables: voiced / semi-voiced pairs first (longest match), then one character-wise translate."""
+    if kana and ("ﾞ" in text or "ﾟ" in text):
+        for pair, full in _H2Z_V.items():
+            if pair in text:
+                text = text.replace(pair, full)
+        for pair, full in _H2Z_S.items():
+            if pair in text:
+                text = text.replace(pair, full)
+    return text.translate(_H2Z_TR[(bool(kana), bool(ascii), bool(digit))])
+
+
+try:        # the reference's recogniser calls jaconv itself: when the package is installed, so do we
+    import jaconv as _jaconv
+except ImportError:
+    _jaconv = None
+
+
 def h2z(text: str, kana: bool = True, ascii: bool = False, digit: bool = False) -> str:
     """Half-width -> full-width (jaconv.h2z semantics: voiced / semi-voiced marks combine with
-    the preceding half-width katakana)."""
-    out: List[str] = []
-    i, n = 0, len(text)
-    while i < n:
-        ch = text[i]
-        if kana:
-            pair = text[i:i + 2]
-            if pair in _H2Z_V:
-                out.append(_H2Z_V[pair]); i += 2; continue
-            if pair in _H2Z_S:
-                out.append(_H2Z_S[pair]); i += 2; continue
-            if ch in _H2Z_K:
-                out.append(_H2Z_K[ch]); i += 1; continue
-        if ascii and ch in _H2Z_A:
-            out.append(_H2Z_A[ch])
-        elif digit and ch in _H2Z_D:
-            out.append(_H2Z_D[ch])
-        else:
-            out.append(ch)
-        i += 1
-    return "".join(out)
+    the preceding half-width katakana).  Uses ``jaconv`` when it is importable, else the restated tables."""
+    if _jaconv is not None:
+        return _jaconv.h2z(text, kana=kana, ascii=ascii, digit=digit)
+    return _h2z_tables(text, kana=kana, ascii=ascii, digit=digit)
 
 
 def post_process(text: str) -> str:
@@ -75,6 +88,10 @@ class Vocab:
     def __init__(self, tokens: Sequence[str]):
         self.tokens = list(tokens)
         self.special_ids = {i for i, t in enumerate(self.tokens) if t in SPECIAL_TOKENS}
+        import numpy as np
+        self._arr = np.array(self.tokens + ["[UNK]"], dtype=object)       # last slot: ids outside the table
+        self._special = np.zeros(len(self.tokens) + 1, dtype=bool)
+        self._special[list(self.special_ids)] = True
 
     @classmethod
     def from_file(cls, path: str) -> "Vocab":
@@ -92,13 +109,12 @@ class Vocab:
         return len(self.tokens)
 
     def decode(self, ids: Iterable[int], skip_special_tokens: bool = True) -> str:
-        toks = []
-        for i in ids:
-            i = int(i)
-            if skip_special_tokens and i in self.special_ids:
-                continue
-            toks.append(self.tokens[i] if 0 <= i < len(self.tokens) else "[UNK]")
-        return " ".join(toks).replace(" ##", "").strip()
+        import numpy as np
+        a = np.asarray(list(ids) if not hasattr(ids, "__len__") else ids, dtype=np.int64).ravel()
+        a = np.where((a >= 0) & (a < len(self.tokens)), a, len(self.tokens))
+        if skip_special_tokens:
+            a = a[~self._special[a]]
+        return " ".join(self._arr[a].tolist()).replace(" ##", "").strip()
 
 
 def ids_to_text(vocab: Vocab, ids: Iterable[int]) -> str:

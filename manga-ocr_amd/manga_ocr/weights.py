@@ -228,34 +228,66 @@ def spec_from_hf_config(cfg: dict) -> ModelSpec:
         raise ValueError("encoder/decoder layer_norm_eps differ")
     if dec.get("intermediate_size", 3072) != spec.ffn:
         raise ValueError("encoder/decoder FFN widths differ")
-    for k in ("num_beams",):
-        if int(cfg.get(k, dec.get(k, 1)) or 1) != 1:
-            raise ValueError("checkpoint asks for beam search; the engine implements greedy decode only")
+    # The published checkpoint's config.json is recalled to carry generation defaults of its training script
+    # (num_beams=4, no_repeat_ngram_size=3, length_penalty=2.0, early_stopping=true) [RECALL]; BASELINE.json's
+    # north_star fixes GREEDY decode, so the engine decodes greedily and says so once (warn, not fail).
+    non_greedy = {}
+    for k, dflt in (("num_beams", 1), ("no_repeat_ngram_size", 0), ("length_penalty", 1.0), ("do_sample", False),
+                    ("repetition_penalty", 1.0), ("num_beam_groups", 1)):
+        v = cfg.get(k, dec.get(k, dflt))
+        if v is not None and v != dflt:
+            non_greedy[k] = v
+    if non_greedy:
+        import warnings
+        warnings.warn("checkpoint config asks for non-greedy generation " + repr(non_greedy) +
+                      "; this engine implements greedy decode (generate(do_sample=False, num_beams=1)) and ignores it",
+                      RuntimeWarning, stacklevel=2)
     return spec
 
 
-def load_checkpoint(model_dir: str) -> Tuple[ModelSpec, Dict[str, np.ndarray]]:
-    """Read ``config.json`` + ``model.safetensors`` (or ``pytorch_model.bin``) from a local
-    directory and return (spec, canonical float32 weights)."""
-    with open(os.path.join(model_dir, "config.json"), "r", encoding="utf-8") as f:
-        cfg = json.load(f)
-    spec = spec_from_hf_config(cfg)
-    raw: Dict[str, np.ndarray] = {}
+def _read_state_dict(model_dir: str) -> Dict[str, np.ndarray]:
+    """Every floating-point tensor of the checkpoint as float32 (integer buffers such as the 4.x
+    ``decoder.bert.embeddings.position_ids`` are not parameters and are dropped)."""
     st = os.path.join(model_dir, "model.safetensors")
     if os.path.exists(st):
-        from safetensors.numpy import load_file
-        raw = {k: np.asarray(v) for k, v in load_file(st).items()}
-    else:
-        import torch
-        sd = torch.load(os.path.join(model_dir, "pytorch_model.bin"), map_location="cpu", weights_only=True)
-        raw = {k: v.float().numpy() for k, v in sd.items()}
-    w = {canonical_name(k): np.ascontiguousarray(v, dtype=np.float32) for k, v in raw.items()}
+        try:
+            from safetensors.numpy import load_file
+            raw = load_file(st)
+            return {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in raw.items() if np.issubdtype(v.dtype, np.floating)}
+        except (TypeError, ValueError, KeyError):       # bf16 storage: numpy has no such dtype, go through torch
+            from safetensors.torch import load_file as load_torch
+            return {k: v.float().numpy() for k, v in load_torch(st).items() if v.is_floating_point()}
+    pt = os.path.join(model_dir, "pytorch_model.bin")
+    if not os.path.exists(pt):
+        raise FileNotFoundError(f"neither model.safetensors nor pytorch_model.bin in {model_dir}")
+    import torch
+    sd = torch.load(pt, map_location="cpu", weights_only=True)
+    return {k: v.float().numpy() for k, v in sd.items() if hasattr(v, "is_floating_point") and v.is_floating_point()}
+
+
+def load_checkpoint(model_dir: str) -> Tuple[ModelSpec, Dict[str, np.ndarray]]:
+    """Read ``config.json`` (+ ``generation_config.json``) and ``model.safetensors`` (or ``pytorch_model.bin``)
+    from a local directory and return (spec, canonical float32 weights).  Accepts the transformers-4.x key
+    spelling the published checkpoint was saved with and the 5.x one (``TF/conversion_mapping.py:338-346``), a
+    tied or untied vocabulary projection (``TF/models/bert/modeling_bert.py:825-828``) and either spelling of
+    its bias (``decoder.cls.predictions.bias`` / ``...decoder.bias``)."""
+    with open(os.path.join(model_dir, "config.json"), "r", encoding="utf-8") as f:
+        cfg = json.load(f)
+    gen = os.path.join(model_dir, "generation_config.json")
+    if os.path.exists(gen):        # generation defaults moved there in later transformers releases; config.json wins
+        with open(gen, "r", encoding="utf-8") as f:
+            for k, v in json.load(f).items():
+                cfg.setdefault(k, v)
+    spec = spec_from_hf_config(cfg)
+    w = {canonical_name(k): v for k, v in _read_state_dict(model_dir).items()}
     lm_w = "decoder.cls.predictions.decoder.weight"
     lm_b = "decoder.cls.predictions.decoder.bias"
     if lm_w not in w:  # tied head
         w[lm_w] = w["decoder.bert.embeddings.word_embeddings.weight"].copy()
     if lm_b not in w:
         w[lm_b] = w["decoder.cls.predictions.bias"]
+    wanted = {name for name, _, _ in tensor_table(spec)}
+    w = {k: v for k, v in w.items() if k in wanted}      # pooler, duplicated bias, buffers: not consumed
     check_weights(w, spec)
     return spec, w
 

@@ -79,8 +79,32 @@ def test_checkpoint_key_renames_and_config_checks():
     cfg = {"encoder": {}, "decoder": {"vocab_size": 6144, "num_hidden_layers": 2}, "decoder_start_token_id": 2,
            "eos_token_id": 3, "pad_token_id": 0, "max_length": 300}
     assert spec_from_hf_config(cfg) == DEFAULT_SPEC
+    # the published config carries its training script's beam-search defaults [RECALL]; north_star fixes greedy:
+    # the loader says so once and goes on
+    with pytest.warns(RuntimeWarning, match="greedy"):
+        assert spec_from_hf_config({**cfg, "num_beams": 4, "no_repeat_ngram_size": 3, "length_penalty": 2.0}) == DEFAULT_SPEC
     with pytest.raises(ValueError):
-        spec_from_hf_config({**cfg, "num_beams": 4})
+        spec_from_hf_config({**cfg, "encoder": {"hidden_act": "gelu_new"}})
+
+
+def test_load_checkpoint_end_to_end_from_a_synthetic_hf_directory(tmp_path):
+    """4.x key spelling, tied LM head, bias under its 4.x name, pooler + position_ids present, num_beams=4 in
+    config.json: every line of load_checkpoint runs, and the result equals the generator's canonical weights."""
+    from hf_dir import write_hf_dir
+    from manga_ocr.weights import load_checkpoint
+    d = str(tmp_path / "manga-ocr-base")
+    want = write_hf_dir(d, seed=3, eos_bias=0.5)
+    from safetensors.numpy import load_file
+    stored = load_file(os.path.join(d, "model.safetensors"))
+    assert "decoder.cls.predictions.decoder.weight" not in stored and "encoder.encoder.layer.0.attention.attention.query.weight" in stored
+    with pytest.warns(RuntimeWarning, match="greedy"):
+        spec, got = load_checkpoint(d)
+    assert spec == DEFAULT_SPEC
+    assert set(got) == set(want)
+    for k in want:
+        np.testing.assert_array_equal(got[k], want[k], err_msg=k)
+    v = text.Vocab.from_file(text.find_vocab(d))
+    assert len(v) == spec.vocab
 
 
 def test_post_process_known_answers():
@@ -91,6 +115,8 @@ def test_post_process_known_answers():
     assert text.post_process("あ…い") == "あ．．．い"
     assert text.post_process("あ・・・い・う") == "あ．．．い・う"
     assert text.post_process("え . . 。") == "え．．。"
+    assert text.post_process('"a\'b" \\ `') == "”ａ’ｂ”￥‘"          # jaconv's typographic partners [RECALL]
+    assert text._h2z_tables("ｳﾞｧ ﾎﾟ ｶ", ascii=True, digit=True) == "ヴァ　ポ　カ"
     assert len(text._HALF_ASCII) == len(text._FULL_ASCII) and len(text._HALF_KANA) == len(text._FULL_KANA)
 
 
