@@ -132,6 +132,7 @@ struct mocr_engine : LaneCtx {
     std::mutex err_mu;              // guards err: mocr_last_error may be called while another thread fails
     bool poisoned = false;          // a HIP call failed: HIP errors are sticky, so every later call is refused
     bool committed = false;
+    int gen_max_len = 0;            // generate(max_length) of the device-buffer submissions (mocr_set_generate_max_length)
     bool latent = false;            // bf16 engines: latent (absorbed) decode attention ...
     int classic_rows = 0;           // ... for batches of more than this many rows; smaller ones use the classic kernels
     int Bc = 0;                     // rows the classic K/V buffers are sized for
@@ -559,7 +560,8 @@ void latent_attn(mocr_engine* e, bool self, int layer, int n, int approx_len) {
     ProfScope ps(e, self ? "lat_attn_self" : "lat_attn_cross", 4.0 * n * 16 * approx_len * e->D,
                  (double)n * approx_len * e->D * 2 + 2.0 * n * e->H * e->D * 2);     // keys + Qt in + Et out (12 heads)
     static const int lat_blocks = env_int("MOCR_LAT_BLOCKS", 256);
-    hipLaunchKernelGGL(latent_attn_kernel, dim3(std::min(n, lat_blocks)), dim3(256), LAT_LDS, e->stream, p);
+    if (self) hipLaunchKernelGGL(latent_attn_kernel<true>, dim3(std::min(n, lat_blocks)), dim3(256), LAT_LDS, e->stream, p);
+    else hipLaunchKernelGGL(latent_attn_kernel<false>, dim3(std::min(n, lat_blocks)), dim3(256), LAT_LDS, e->stream, p);
     HIPCHECK(hipGetLastError());
 }
 
@@ -698,7 +700,8 @@ template <typename T> void init_kernel_attrs() {
     set_max_lds(gemm256_kernel<EPI_BIAS_RESID>, l256);
     set_max_lds(gemm256_kernel<EPI_PATCH>, l256);
     set_max_lds(gemm256_kernel<EPI_BIAS_F32>, l256);
-    set_max_lds(latent_attn_kernel, LAT_LDS);
+    set_max_lds(latent_attn_kernel<true>, LAT_LDS);
+    set_max_lds(latent_attn_kernel<false>, LAT_LDS);
 }
 
 // `steps` consecutive greedy steps captured once and replayed: every per-step value (position,
@@ -852,9 +855,23 @@ bool pump_once(mocr_engine* e) {
             L.jobs.clear();
             L.n = 0;
             L.max_len = e->pending.front().max_len;
+            // An idle lane takes as many queued requests as fit in max_batch rows.  When SEVERAL lanes are idle and the
+            // queue would fit into fewer of them, it is split evenly over the idle lanes as long as every part keeps
+            // >= SPLIT_MIN rows: two fat batches in flight overlap each other's latency-bound phases (+6 % at 2 x 2560
+            // against 1 x 5120 rows, r02), while below ~1000 rows merging beats overlapping.
+            constexpr long long SPLIT_MIN = 1024;
+            long long rows_pending = 0;
+            for (const Job& p : e->pending) rows_pending += p.n;
+            int idle = 0;
+            for (size_t k = i; k < e->lanes.size(); ++k) idle += e->lanes[k].active ? 0 : 1;
+            long long cap = e->cfg.max_batch;
+            if (idle > 1 && !e->prof_on && rows_pending < (long long)idle * cap) {     // (instrumented passes: one batch, no overlap)
+                const int parts = (int)std::max<long long>(1, std::min<long long>(idle, rows_pending / SPLIT_MIN));
+                cap = std::min<long long>(cap, (rows_pending + parts - 1) / parts);
+            }
             size_t take = 0;
             while (take < e->pending.size() && e->pending[take].max_len == L.max_len &&
-                   L.n + e->pending[take].n <= e->cfg.max_batch) {
+                   (take == 0 || L.n + e->pending[take].n <= cap) && L.n + e->pending[take].n <= e->cfg.max_batch) {
                 L.n += e->pending[take].n;
                 L.jobs.push_back(e->pending[take]);
                 ++take;
@@ -1181,6 +1198,7 @@ int mocr_create(const mocr_config* cfg, mocr_engine** out) {
     mocr_engine* e = new (std::nothrow) mocr_engine();
     if (!e) return MOCR_ERR_NOMEM;
     e->cfg = *cfg;
+    e->gen_max_len = cfg->max_len;
     if (e->cfg.lanes == 0) e->cfg.lanes = 1;
     int rc = guarded(e, [&] {
         int ndev = 0;
@@ -1272,7 +1290,7 @@ int mocr_recognize_device(mocr_engine* e, const void* d_gray, int32_t n, void* d
         HIPCHECK(hipSetDevice(e->cfg.device));
         Job j;
         j.src = reinterpret_cast<const uint8_t*>(d_gray); j.src_host = false;
-        j.n = n; j.max_len = e->cfg.max_len;
+        j.n = n; j.max_len = e->gen_max_len;
         j.out_ids = reinterpret_cast<int32_t*>(d_out_ids); j.out_len = reinterpret_cast<int32_t*>(d_out_len); j.out_host = false;
         submit(e, j);
     });
@@ -1526,6 +1544,14 @@ int mocr_recognize_regions(mocr_engine* e, const mocr_image* pages, int32_t n_pa
     });
 }
 
+int mocr_set_generate_max_length(mocr_engine* e, int32_t max_len) {
+    return guarded(e, [&] {
+        std::lock_guard<std::mutex> lk(e->mu);
+        if (max_len < 2 || max_len > e->cfg.max_len) throw ArgError{"generate max_length must be in [2, max_len]", MOCR_ERR_ARG};
+        e->gen_max_len = max_len;
+    });
+}
+
 int mocr_graph_count(mocr_engine* e) {
     if (!e) return MOCR_ERR_ARG;
     std::lock_guard<std::mutex> lk(e->mu);
@@ -1647,7 +1673,7 @@ int mocr_op_latent_attention(mocr_engine* e, const void* d_qt, const void* d_x, 
         static unsigned long long* dbg = nullptr;
         if (env_int("MOCR_LAT_STAMP", 0)) { if (!dbg) dbg = e->dalloc<unsigned long long>(8 + 512); p.dbg = dbg; }
         ProfScope ps(e, "op_latent", 0, (double)n * len * 1536);
-        hipLaunchKernelGGL(latent_attn_kernel, dim3(std::min((int)n, env_int("MOCR_LAT_BLOCKS", 256))), dim3(256), LAT_LDS, e->stream, p);
+        hipLaunchKernelGGL(latent_attn_kernel<false>, dim3(std::min((int)n, env_int("MOCR_LAT_BLOCKS", 256))), dim3(256), LAT_LDS, e->stream, p);
         HIPCHECK(hipGetLastError());
         HIPCHECK(hipStreamSynchronize(e->stream));
         if (p.dbg) {

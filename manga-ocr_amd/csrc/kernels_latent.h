@@ -172,6 +172,9 @@ __device__ __forceinline__ void lat_stage(const char* src, char* dst, const unsi
 }
 __device__ __forceinline__ int lat_pieces_of(int np, int w) { return (np - w + 2) / 3; }   // #i in 0..15 with w+3i < np (np <= 48)
 
+// SELF only names the instantiation (self: context = step[0] + 1 keys of the per-token cache; cross: the fixed 197
+// encoder rows), so that profiles list the two launches of a decode layer as two kernels.
+template <bool SELF>
 __global__ __launch_bounds__(256, 1) void latent_attn_kernel(LatentParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // plain locals: the lambdas below must not take the address of the kernel-argument struct (that

@@ -175,6 +175,9 @@ class Engine:
         """Asynchronous; all three are device buffers (torch CUDA tensors or raw addresses)."""
         self._check(self.lib.mocr_recognize_device(self._h, _ptr(d_gray), n, _ptr(d_out_ids), _ptr(d_out_len)))
 
+    def set_generate_max_length(self, max_len: int) -> None:
+        self._check(self.lib.mocr_set_generate_max_length(self._h, int(max_len)))
+
     def recognize_gray(self, gray: np.ndarray, max_len: Optional[int] = None) -> Tuple[np.ndarray, np.ndarray]:
         a = np.ascontiguousarray(gray, dtype=np.uint8)
         n = a.shape[0]

@@ -113,19 +113,43 @@ class _Batcher:
         self._thread.join(timeout=5)
 
 
+# HBM one row of a lane's workspace takes (bf16): 197 encoder rows x (fp32 residual + LN out + QKV + context + FFN
+# intermediate + encoder output = 18,432 B) + latent key/value rows + input planes
+_BYTES_PER_ROW_PER_LANE = 197 * 18432 + 2 * 300 * 768 * 2 + 4 * 224 * 224
+
+
+def default_max_batch(device: int, lanes: int) -> int:
+    """Rows per internal batch when the caller does not say: as fat as a fifth of the free HBM allows, capped at
+    2048 (decode throughput is bought with fat batches - DESIGN.md §5 - and flattens beyond that), at least 64."""
+    from .engine import device_memory
+    free, _total = device_memory(device)
+    rows = int(free * 0.2 / (max(1, lanes) * _BYTES_PER_ROW_PER_LANE))
+    return max(64, min(2048, rows // 64 * 64))
+
+
 class MangaOcr:
     def __init__(self, pretrained_model_name_or_path: str = DEFAULT_MODEL, force_cpu: bool = False, *,
-                 dtype: Optional[str] = None, device: Optional[int] = None, max_batch: Optional[int] = None,
-                 batch_timeout_ms: float = 2.0, synthetic_seed: Optional[int] = None):
+                 dtype: Optional[str] = None, device: Optional[int] = None, devices: Optional[Sequence[int]] = None,
+                 max_batch: Optional[int] = None, lanes: Optional[int] = None, batch_timeout_ms: float = 2.0,
+                 synthetic_seed: Optional[int] = None):
+        """``MangaOcr()`` as the application calls it (``src/ui/main_window.py:3394``) builds the engine on this
+        process's GPU with two lanes and an internal batch sized from the free HBM.  ``devices=[0, 1, ...]`` (or
+        ``MANGA_OCR_DEVICES=0,1,...``) instead starts one child process per GPU and shards every batch call over
+        them (``manga_ocr/multi.py``); the parent then never touches a GPU."""
         if force_cpu:
             raise RuntimeError("this MangaOcr is the MI355X engine: there is no CPU path (force_cpu=True is not supported)")
         dtype = dtype or os.environ.get("MANGA_OCR_DTYPE", "bf16")
+        if devices is None and os.environ.get("MANGA_OCR_DEVICES"):
+            devices = [int(x) for x in os.environ["MANGA_OCR_DEVICES"].split(",") if x.strip() != ""]
         device = int(os.environ.get("LOCAL_RANK", "0")) if device is None else device
-        max_batch = int(max_batch or os.environ.get("MANGA_OCR_MAX_BATCH", "64"))
+        lanes = int(lanes or os.environ.get("MANGA_OCR_LANES", "2"))
+        if max_batch is None and os.environ.get("MANGA_OCR_MAX_BATCH"):
+            max_batch = int(os.environ["MANGA_OCR_MAX_BATCH"])
         if synthetic_seed is None and os.environ.get("MANGA_OCR_SYNTHETIC"):
             synthetic_seed = int(os.environ["MANGA_OCR_SYNTHETIC"])
+        model_dir = None
         if synthetic_seed is not None:
-            spec, weights, vocab = DEFAULT_SPEC, synthetic_weights(synthetic_seed), Vocab.synthetic(DEFAULT_SPEC.vocab)
+            spec, weights, vocab = DEFAULT_SPEC, None, Vocab.synthetic(DEFAULT_SPEC.vocab)
         else:
             model_dir = _resolve_model_dir(str(pretrained_model_name_or_path))
             if model_dir is None:
@@ -140,7 +164,19 @@ class MangaOcr:
             if len(vocab) != spec.vocab:
                 raise ValueError(f"vocab.txt has {len(vocab)} entries, config says {spec.vocab}")
         self.spec, self.vocab = spec, vocab
-        self.engine = Engine(weights, spec, dtype=dtype, device=device, max_batch=max_batch)
+        if devices is not None and len(devices) > 1:
+            from .multi import MultiGpuEngine
+            max_batch = int(max_batch or 2048)
+            self.engine = MultiGpuEngine(devices, factory_args=dict(synthetic_seed=synthetic_seed, model_dir=model_dir, dtype=dtype,
+                                                                    max_batch=max_batch, lanes=lanes))
+        else:
+            if devices:
+                device = int(devices[0])
+            if weights is None:
+                weights = synthetic_weights(synthetic_seed)
+            max_batch = int(max_batch or default_max_batch(device, lanes))
+            self.engine = Engine(weights, spec, dtype=dtype, device=device, max_batch=max_batch, lanes=lanes)
+        self.max_batch = max_batch
         self._batcher = _Batcher(self.engine, max_batch, batch_timeout_ms)
         # same warm-up the reference's recogniser does in its constructor (one inference)
         self.recognize_ids([np.zeros((spec.image_size, spec.image_size), dtype=np.uint8)])
@@ -158,15 +194,42 @@ class MangaOcr:
         return ids_to_text(self.vocab, ids)
 
     # ------------------------------------------------------------------ batch surface (callers that hold many crops)
-    def recognize_ids(self, crops: Sequence[np.ndarray]) -> List[np.ndarray]:
-        """uint8 crops of any sizes ([h,w] luminance or [h,w,3] RGB) -> token ids (without padding)."""
-        ids, lens = self.engine.recognize_images(list(crops))
+    def recognize_ids(self, crops: Sequence[np.ndarray], bgr: bool = False) -> List[np.ndarray]:
+        """uint8 crops of any sizes ([h,w] luminance or [h,w,3] RGB; BGR with ``bgr=True``) -> token ids (without padding)."""
+        ids, lens = self.engine.recognize_images(list(crops), bgr)
         return [ids[i, :lens[i]].copy() for i in range(len(lens))]
 
     def recognize_batch(self, images: Sequence) -> List[str]:
         """All crops of a page (or chapter) at once - what ``_collect_manga_detections``
         (``src/ui/main_window.py:9462-9476``) does one region at a time."""
         return [ids_to_text(self.vocab, r) for r in self.recognize_ids([to_pixels(im) for im in images])]
+
+    def recognize_batch_arrays(self, crops: Sequence[np.ndarray]) -> List[str]:
+        """uint8 arrays ([h,w] luminance or [h,w,3] RGB, any sizes) -> strings: what a caller that already holds numpy
+        crops (the crop-job queue) uses instead of wrapping each one in a PIL image."""
+        return [ids_to_text(self.vocab, r) for r in self.recognize_ids(list(crops))]
+
+    def recognize_bgr(self, crops_bgr: Sequence[np.ndarray]) -> List[str]:
+        """BGR crops exactly as the crop tools and the worker hold them (``cropped_cv_img``, ``src/core/workers.py:300``):
+        the BGR -> RGB swap of ``src/ui/main_window.py:9800`` is folded into the device's luminance conversion."""
+        return [ids_to_text(self.vocab, r) for r in self.recognize_ids(list(crops_bgr), bgr=True)]
+
+    def recognize_regions(self, pages_bgr: Sequence[np.ndarray], regions) -> List[str]:
+        """``regions``: (page_index, x, y, w, h) bounding rectangles on BGR pages; every page is uploaded once and
+        the padded crops (``src/ui/main_window.py:9530-9540``) are cut on the device.  One string per region
+        ('' for a region reduced to a sliver, like the reference)."""
+        ids, lens = self.engine.recognize_regions(list(pages_bgr), list(regions), True)
+        return [ids_to_text(self.vocab, ids[i, :lens[i]]) if lens[i] > 0 else "" for i in range(len(lens))]
+
+    def recognize_page(self, page_bgr: np.ndarray, regions):
+        """``_collect_manga_detections`` for one page: ``regions`` = the detector's (text, polygon) pairs."""
+        from .regions import recognize_page
+        return recognize_page(self, page_bgr, regions)
+
+    def recognize_pages(self, pages_bgr, regions_per_page, on_error=None):
+        """``AutoDetectorWorker.run`` (Text mode) over several pages: one job queue for all regions of all pages."""
+        from .regions import recognize_pages
+        return recognize_pages(self, pages_bgr, regions_per_page, on_error)
 
     def close(self) -> None:
         self._batcher.close()

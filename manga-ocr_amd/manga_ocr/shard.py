@@ -22,23 +22,18 @@ def shard_bounds(n: int, world: int, rank: int) -> Tuple[int, int]:
     return lo, lo + q + (1 if rank < r else 0)
 
 
-def recognize_sharded(gray: np.ndarray, recognize: Callable[[np.ndarray], Tuple[np.ndarray, np.ndarray]],
-                      max_len: int = 300, group=None, device: Optional[str] = None) -> Tuple[np.ndarray, np.ndarray]:
-    """gray: the WHOLE job queue, uint8 [N,224,224], identical on every rank (or only this rank's
-    shard is touched - rows outside [lo,hi) are never read).  ``recognize`` maps a shard to
-    (ids int32 [n,max_len], lens int32 [n]) - normally ``Engine.recognize``.
-    Returns (ids [N,max_len], lens [N]) on every rank."""
+def gather_rows(ids: Optional[np.ndarray], lens: Optional[np.ndarray], n: int, max_len: int = 300, group=None,
+                device: Optional[str] = None) -> Tuple[np.ndarray, np.ndarray]:
+    """THE exchange step: this rank's decoded shard (rows [lo, hi) of a queue of n, `shard_bounds`) -> the whole queue
+    on every rank, with ONE all-gather of a fixed-size int32 [n_local_max, max_len + 1] block (the last column
+    carries the row length)."""
     import torch
     import torch.distributed as dist
-    if not dist.is_available() or not dist.is_initialized():
-        return recognize(gray)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    n = int(gray.shape[0])
     lo, hi = shard_bounds(n, world, rank)
-    n_max = -(-n // world)
-    block = np.zeros((n_max, max_len + 1), dtype=np.int32)        # last column carries the row length
+    n_max = max(1, -(-n // world))
+    block = np.zeros((n_max, max_len + 1), dtype=np.int32)
     if hi > lo:
-        ids, lens = recognize(gray[lo:hi])
         block[:hi - lo, :max_len] = ids
         block[:hi - lo, max_len] = lens
     if device is None:
@@ -54,6 +49,24 @@ def recognize_sharded(gray: np.ndarray, recognize: Callable[[np.ndarray], Tuple[
         ids_all[a:b] = out[r, :b - a, :max_len]
         lens_all[a:b] = out[r, :b - a, max_len]
     return ids_all, lens_all
+
+
+def recognize_sharded(gray: np.ndarray, recognize: Callable[[np.ndarray], Tuple[np.ndarray, np.ndarray]],
+                      max_len: int = 300, group=None, device: Optional[str] = None) -> Tuple[np.ndarray, np.ndarray]:
+    """gray: the WHOLE job queue, uint8 [N,224,224], identical on every rank (or only this rank's
+    shard is touched - rows outside [lo,hi) are never read).  ``recognize`` maps a shard to
+    (ids int32 [n,max_len], lens int32 [n]) - normally ``Engine.recognize``.
+    Returns (ids [N,max_len], lens [N]) on every rank."""
+    import torch.distributed as dist
+    if not dist.is_available() or not dist.is_initialized():
+        return recognize(gray)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n = int(gray.shape[0])
+    lo, hi = shard_bounds(n, world, rank)
+    ids = lens = None
+    if hi > lo:
+        ids, lens = recognize(gray[lo:hi])
+    return gather_rows(ids, lens, n, max_len, group, device)
 
 
 def texts_from_ids(vocab, ids: np.ndarray, lens: Sequence[int]) -> List[str]:

@@ -135,7 +135,7 @@ def tensor_table(spec: ModelSpec = DEFAULT_SPEC) -> List[TensorRow]:
 
 def synthetic_weights(seed: int = 0, spec: ModelSpec = DEFAULT_SPEC, *, std: float = 0.02,
                       bias_std: float = 0.02, ln_std: float = 0.1, tie_lm_head: bool = True,
-                      eos_bias: float = 0.0, logit_scale: float = 1.0) -> Dict[str, np.ndarray]:
+                      eos_bias: float = 0.0, logit_scale: float = 1.0, vocab_bias_std: float = 0.0) -> Dict[str, np.ndarray]:
     """Deterministic synthetic parameters (float32).
 
     One ``numpy.random.RandomState(seed)`` stream (frozen algorithm), tensors drawn
@@ -148,8 +148,12 @@ def synthetic_weights(seed: int = 0, spec: ModelSpec = DEFAULT_SPEC, *, std: flo
     stream position of later tensors does not depend on the flag).
     ``eos_bias`` is added to the vocabulary bias of ``eos_id`` (makes rows finish at
     different steps: exercises the finished-row padding rule).  ``logit_scale``
-    multiplies the vocabulary projection weight (widens top-1 margins so that a
-    bf16 engine's token ids are comparable with the fp32 oracle's).
+    multiplies the vocabulary projection weight (it scales the logits' rounding noise
+    by the same factor, so it does NOT make a bf16 engine's ids more comparable with an
+    fp32 oracle's - kept for completeness).  ``vocab_bias_std`` adds an independent
+    N(0, vocab_bias_std^2) term (its own RandomState(seed + 7919) stream) to the fp32
+    vocabulary bias: exact in every engine, it widens the top-2 margins relative to the
+    bf16 noise of the matrix products - the widened-margin weights of the bf16 id tests.
     """
     rs = np.random.RandomState(seed)
     out: Dict[str, np.ndarray] = {}
@@ -172,6 +176,10 @@ def synthetic_weights(seed: int = 0, spec: ModelSpec = DEFAULT_SPEC, *, std: flo
         out[lm_w] = out["decoder.bert.embeddings.word_embeddings.weight"].copy()
     if logit_scale != 1.0:
         out[lm_w] = (out[lm_w] * np.float32(logit_scale)).astype(np.float32)
+    if vocab_bias_std != 0.0:
+        extra = np.random.RandomState(seed + 7919).standard_normal(spec.vocab) * vocab_bias_std
+        extra[[spec.pad_id, spec.eos_id]] = -abs(extra).max()      # rows keep decoding: neither EOS nor PAD gets a head start
+        out[lm_b] = (out[lm_b] + extra.astype(np.float32)).astype(np.float32)
     if eos_bias != 0.0:
         out[lm_b] = out[lm_b].copy()
         out[lm_b][spec.eos_id] += np.float32(eos_bias)
