@@ -255,7 +255,11 @@ def main():
     if extras and not args.no_profile:
         eng.profile_enable(True)
         eng.profile_reset()
-        psteps = max(1, min(args.max_batch // B, steps_timed))   # ONE merged internal batch: durations free of overlap
+        # ONE internal batch of the shape the timed region's lanes ran (the engine splits a queue over its idle lanes
+        # while every part keeps >= 1024 rows), alone on the GPU: durations free of overlap
+        rows_q = min(args.max_batch * args.lanes, steps_timed * B)
+        parts = max(1, min(args.lanes, rows_q // 1024))
+        psteps = max(1, min(args.max_batch // B, -(-steps_timed // parts)))
         for i in range(psteps):
             eng.recognize_device(d_gray, B, d_ids[i % K], d_len[i % K])
         eng.synchronize()

@@ -302,6 +302,32 @@ void launch_gemm_wide_t(mocr_engine* e, const GemmParams& p0) {
     HIPCHECK(hipGetLastError());
 }
 
+template <int EPI>
+void launch_gemm_wide2_t(mocr_engine* e, const GemmParams& p0) {
+    GemmParams p = p0;
+    p.ntn = p.N / 256;
+    p.ntm = (p.M + 255) / 256;
+    const int grid = (p.ntm * p.ntn + 7) / 8 * 8;
+    // stagger: one tile's duration in units of 1024 cycles: ~1100 cycles per 32-deep K-tile plus the epilogue
+    static const int stagger_env = env_int("MOCR_GEMM_STAGGER", -1);
+    const int tile_units = (p.k_per_split / 32) * 1100 / 1024 + 8;
+    (void)tile_units;
+    p.stagger = stagger_env > 0 ? stagger_env : 0;      // measured r02: no gain (the store drain is not what a phase shift hides), default off
+    p.first_round = e->num_cus;
+    hipLaunchKernelGGL((gemm_wide2_kernel<EPI>), dim3(grid), dim3(512), 4 * (256 + 256) * 64, e->stream, p);
+    HIPCHECK(hipGetLastError());
+}
+
+void launch_gemm_wide2(mocr_engine* e, const GemmParams& p, int epi) {
+    if (p.k_per_split % 64 || p.k_per_split < 128) throw ArgError{"wide2 gemm: K must be a multiple of 64, >= 128", MOCR_ERR_ARG};
+    switch (epi) {
+        case EPI_BIAS: launch_gemm_wide2_t<EPI_BIAS>(e, p); break;
+        case EPI_BIAS_GELU: launch_gemm_wide2_t<EPI_BIAS_GELU>(e, p); break;
+        case EPI_BIAS_RESID: launch_gemm_wide2_t<EPI_BIAS_RESID>(e, p); break;
+        default: throw ArgError{"wide2 gemm: unsupported epilogue", MOCR_ERR_ARG};
+    }
+}
+
 template <int WN>
 void launch_gemm_wide(mocr_engine* e, const GemmParams& p, int epi) {
     switch (epi) {
@@ -321,7 +347,7 @@ void gemm(mocr_engine* e, const char* name, const void* A, int lda, const void* 
           const float* resid, int M, int N, int K, int epi, int tile, int split, long long slab_stride = 0,
           const float* pos = nullptr, int patches = 0, const HeadBatch* hb = nullptr, int group_n = 0, int* cand_idx = nullptr) {
     const int kt = 128 / (int)sizeof(T);
-    if (N % (tile == 1024 ? 256 : tile >= 256 ? 128 : tile) || K % (kt * split) || (split > 1 && epi != EPI_SLAB) ||
+    if (N % (tile >= 1024 ? 256 : tile >= 256 ? 128 : tile) || K % (kt * split) || (split > 1 && epi != EPI_SLAB) ||
         (tile >= 256 && (sizeof(T) != 2 || split != 1)))
         throw ArgError{std::string("gemm shape not tileable: ") + name, MOCR_ERR_ARG};
     GemmParams p{};
@@ -342,12 +368,13 @@ void gemm(mocr_engine* e, const char* name, const void* A, int lda, const void* 
     const double bytes = ((double)M * K + (double)N * K) * sizeof(T) + (double)M * N * out_b * (epi == EPI_SLAB ? split : 1) +
                          (epi == EPI_BIAS_RESID ? (double)M * N * 4 : 0);
     ProfScope ps(e, name, 2.0 * M * N * K * ybatch, bytes * ybatch);
-    if (tile == 1024) launch_gemm_wide<4>(e, p, epi);
+    if (tile == 2048) launch_gemm_wide2(e, p, epi);
+    else if (tile == 1024) launch_gemm_wide<4>(e, p, epi);
     else if (tile == 512) launch_gemm_wide<2>(e, p, epi);
     else if (tile == 256) launch_gemm256(e, p, epi);
     else if (tile == 128) launch_gemm_epi<T, 128, 128>(e, p, epi, split, ybatch);
     else if (tile == 64) launch_gemm_epi<T, 64, 64>(e, p, epi, split, ybatch);
-    else throw ArgError{"gemm tile must be 64, 128, 256, 512 or 1024", MOCR_ERR_ARG};
+    else throw ArgError{"gemm tile must be 64, 128, 256, 512, 1024 or 2048", MOCR_ERR_ARG};
 }
 
 // ---------------------------------------------------------------------------------------- encoder
@@ -406,9 +433,13 @@ void run_encoder(mocr_engine* e, const uint8_t* d_gray, int n) {
     auto layer_tile = [&](int N) {
         if (enc_tile_env) return enc_tile_env;
         const long long tiles = (long long)((M + 255) / 256) * (N / 256);
-        return (sizeof(T) == 2 && tiles >= 3LL * e->num_cus) ? 1024 : 128;
+        return (sizeof(T) == 2 && tiles >= 3LL * e->num_cus) ? 2048 : 128;
     };
-    const int ETQ = layer_tile(3 * D), ETO = layer_tile(D), ET1 = layer_tile(F);
+    // per-GEMM overrides for experiments: MOCR_ENC_TILE_QKV / _O / _FC1 / _FC2 (tile codes as in gemm())
+    static const int tq_env = env_int("MOCR_ENC_TILE_QKV", 0), to_env = env_int("MOCR_ENC_TILE_O", 0),
+                     t1_env = env_int("MOCR_ENC_TILE_FC1", 0), t2_env = env_int("MOCR_ENC_TILE_FC2", 0);
+    const int ETQ = tq_env ? tq_env : layer_tile(3 * D), ETO = to_env ? to_env : layer_tile(D), ET1 = t1_env ? t1_env : layer_tile(F);
+    const int ET2 = t2_env ? t2_env : ETO;
     gemm<T>(e, "gemm_patch_embed", e->Hb, P * P, w.wpe, w.bpe, e->X, D, nullptr, MPATCH, D, P * P, EPI_PATCH, ET, 1, 0,
             w.pos_enc, NP);
     const int impl = (e->cfg.flags & MOCR_FLAG_SIMPLE_ATTENTION) ? 0 : 1;
@@ -420,7 +451,7 @@ void run_encoder(mocr_engine* e, const uint8_t* d_gray, int n) {
         gemm<T>(e, "gemm_enc_oproj", e->CTX, D, L.wo, L.bo, e->X, D, e->X, M, D, D, EPI_BIAS_RESID, ETO, 1);
         layernorm<T>(e, e->X, L.ln2g, L.ln2b, e->Xn, M);
         gemm<T>(e, "gemm_enc_fc1", e->Xn, D, L.w1, L.b1, e->Hb, F, nullptr, M, F, D, EPI_BIAS_GELU, ET1, 1, 0, nullptr, 0, nullptr, 12);
-        gemm<T>(e, "gemm_enc_fc2", e->Hb, F, L.w2, L.b2, e->X, D, e->X, M, D, F, EPI_BIAS_RESID, ETO, 1);
+        gemm<T>(e, "gemm_enc_fc2", e->Hb, F, L.w2, L.b2, e->X, D, e->X, M, D, F, EPI_BIAS_RESID, ET2, 1);
     }
     layernorm<T>(e, e->X, w.lnfg, w.lnfb, e->ENC, M);
 }
@@ -428,7 +459,9 @@ void run_encoder(mocr_engine* e, const uint8_t* d_gray, int n) {
 // ---------------------------------------------------------------------------------------- decoder
 static int dec_tile(int rows) {
     static const int forced = env_int("MOCR_DEC_TILE", 0);
-    static const int fat = env_int("MOCR_DEC_FAT_ROWS", 256);
+    // 128 x 128 tiles from 512 rows (r02: at 256 rows the 64 x 64 tiles need a third of the split-K slabs - 113 -> 101 ms
+    // for an isolated 256-crop batch)
+    static const int fat = env_int("MOCR_DEC_FAT_ROWS", 512);
     if (forced) return forced;
     return rows >= fat ? 128 : 64;
 }
@@ -695,6 +728,9 @@ template <typename T> void init_kernel_attrs() {
     set_max_lds(gemm_wide_kernel<EPI_BIAS, 4>, 3 * (256 + 256) * 64);
     set_max_lds(gemm_wide_kernel<EPI_BIAS_GELU, 4>, 3 * (256 + 256) * 64);
     set_max_lds(gemm_wide_kernel<EPI_BIAS_RESID, 4>, 3 * (256 + 256) * 64);
+    set_max_lds(gemm_wide2_kernel<EPI_BIAS>, 4 * (256 + 256) * 64);
+    set_max_lds(gemm_wide2_kernel<EPI_BIAS_GELU>, 4 * (256 + 256) * 64);
+    set_max_lds(gemm_wide2_kernel<EPI_BIAS_RESID>, 4 * (256 + 256) * 64);
     set_max_lds(gemm256_kernel<EPI_BIAS>, l256);
     set_max_lds(gemm256_kernel<EPI_BIAS_GELU>, l256);
     set_max_lds(gemm256_kernel<EPI_BIAS_RESID>, l256);

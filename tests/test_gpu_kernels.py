@@ -57,9 +57,9 @@ def test_gemm_epilogues(dtype, tile, M, N, K, epi):
     assert err <= tol
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 768), (700, 2304, 768), (1000, 768, 3072), (256, 768, 256)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 768), (700, 2304, 768), (1000, 768, 3072), (256, 768, 256), (300, 512, 128)])
 @pytest.mark.parametrize("epi", [EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_BIAS_F32])
-@pytest.mark.parametrize("tile", [256, 512, 1024])
+@pytest.mark.parametrize("tile", [256, 512, 1024, 2048])
 def test_gemm_256x128_three_stage_ring(M, N, K, epi, tile):
     """The big-tile encoder kernels (bf16 only; 256 = 64-deep K-tiles, epilogue through LDS; 512 = the
     "wide" kernel: 32-deep K-tiles, two blocks per CU, epilogue from the registers): K from 1 to 96
@@ -67,6 +67,10 @@ def test_gemm_256x128_three_stage_ring(M, N, K, epi, tile):
     256 exercises the row guard."""
     if tile >= 512 and epi == EPI_BIAS_F32:
         pytest.skip("the wide kernel has the encoder layers' epilogues only")
+    if tile == 2048 and K < 128:
+        pytest.skip("the four-stage wide kernel (tile code 2048: fragments requested across the K-tile barrier) needs >= 4 K-tiles")
+    if tile != 2048 and K == 128:
+        pytest.skip("shape added for the four-stage kernel's shortest K loop")
     eng = engine("bf16")
     rs = np.random.RandomState(M + N + K + epi)
     Mp = (M + 255) // 256 * 256

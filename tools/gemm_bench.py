@@ -32,7 +32,7 @@ def enc_shapes(M):
     out = []
     for name, N, K, epi in (("enc_qkv", 2304, 768, "bias"), ("enc_oproj", 768, 768, "resid"), ("enc_fc1", 3072, 768, "gelu"),
                             ("enc_fc2", 768, 3072, "resid")):
-        for tile in (128, 256, 512, 1024):
+        for tile in (128, 256, 512, 1024, 2048):
             out.append((f"{name} t{tile}", M, N, K, epi, tile, 1))
     return out
 
@@ -46,8 +46,9 @@ def main():
             shapes = [s for s in shapes if sys.argv[3] in s[0]]
     for name, M, N, K, epi, tile, split in shapes:
         Mp = (M + 255) // 256 * 256
-        A = (torch.randn(Mp, K, device="cuda") * 0.5).to(torch.bfloat16)
-        W = (torch.randn(N, K, device="cuda") * 0.05).to(torch.bfloat16)
+        zero = bool(os.environ.get("GEMM_BENCH_ZEROS"))      # all-zero operands: the clock the chip holds is data-dependent
+        A = (torch.randn(Mp, K, device="cuda") * (0.0 if zero else 0.5)).to(torch.bfloat16)
+        W = (torch.randn(N, K, device="cuda") * (0.0 if zero else 0.05)).to(torch.bfloat16)
         bias = torch.randn(N, device="cuda")
         out_f32 = epi in ("slab", "resid", "f32")
         out = torch.zeros((split if epi == "slab" else 1) * M, N, device="cuda", dtype=torch.float32 if out_f32 else torch.bfloat16)

@@ -1,12 +1,23 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 output (gpurun_out/<dir>/*.csv) into the small files kept under profiles/.
 
-    python tools/summarize_profiles.py --round r01 --stats gpurun_out/prof3 --fetch gpurun_out/pmc_fetch --write gpurun_out/pmc_write
+    python tools/summarize_profiles.py --round r02 --rows 2560 --stats <dir> --fetch <dir> --write <dir> [--note ...]
 
-* <round>_kernel_stats.csv : rocprofv3 --kernel-trace --stats summary, verbatim (per-kernel calls / avg ns)
-* <round>_pmc_traffic.json : per kernel, average FETCH_SIZE / WRITE_SIZE per launch (separate --pmc passes)
-  and the corrected HBM traffic:  (2 * FETCH_SIZE + WRITE_SIZE) * 1024 bytes - on gfx950 FETCH_SIZE counts
-  half of a wide (16 B/lane) coalesced read stream (MI355X_MICROARCH.md, HBM section).
+All three passes run the SAME command (one lane, no warm-up shape, timed region only):
+    rocprofv3 --kernel-trace --stats --output-format csv -d <dir> -- python bench.py --steps 10 --warmup 0 --lanes 1 --only-timed
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d <dir> -- python bench.py ...        (own pass: TCC has 4 slots, FETCH_SIZE takes 3)
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d <dir> -- python bench.py ...
+so every launch in them belongs to an internal batch of `--rows` rows decoding alone (kernel durations free of
+overlap), the shape bench.py's instrumented pass measures with HIP events.
+
+* <round>_kernel_stats.csv   : the rocprofv3 --stats summary, verbatim
+* <round>_kernel_classes.json: per kernel CLASS as bench.py names it (the latent attention is two instantiations,
+                               latent_attn_kernel<true> = self, <false> = cross): calls, avg / min / max ns
+* <round>_pmc_traffic.json   : by_rows[rows][class] = FETCH_SIZE / WRITE_SIZE per launch and the corrected HBM bytes
+      traffic_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024   (gfx950: FETCH_SIZE counts half of a wide
+      16 B/lane read stream; WRITE_SIZE is exact - MI355X_MICROARCH.md, HBM section)
+  next to the algorithmic bytes per launch, so that roofline.frac = algorithmic / avg_ns / 8 TB/s and
+  traffic / algorithmic can be recomputed from these files alone.
 """
 import argparse
 import collections
@@ -17,41 +28,93 @@ import shutil
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
+CLASSES = [  # (substring of the kernel symbol, bench.py's class name)
+    ("latent_attn_kernel<true>", "lat_attn_self"), ("latent_attn_kernel<false>", "lat_attn_cross"),
+    ("latent_attn_fp8_kernel<true>", "lat8_attn_self"), ("latent_attn_fp8_kernel<false>", "lat8_attn_cross"),
+    ("dec_qqt_kernel", "dec_qqt"), ("enc_attn_mfma_kernel", "enc_attn_mfma"), ("layernorm_kernel", "layernorm"),
+    ("dec_add_ln_kernel", "dec_add_ln"), ("dec_token_kernel", "dec_token"), ("gemm_wide2_kernel", "gemm_enc_layers(wide2)"),
+]
+
+
+def klass(name):
+    for sub, c in CLASSES:
+        if sub in name:
+            return c
+    return None
+
+
+def find(path, suffix):
+    for d, _, files in os.walk(path):
+        for f in files:
+            if f.endswith(suffix):
+                return os.path.join(d, f)
+    raise FileNotFoundError(f"no *{suffix} under {path}")
+
 
 def pmc(path):
-    f = [p for p in os.listdir(path) if p.endswith("counter_collection.csv")][0]
     agg = collections.defaultdict(lambda: [0, 0.0])
-    for r in csv.DictReader(open(os.path.join(path, f))):
-        a = agg[r["Kernel_Name"]]
-        a[0] += 1
-        a[1] += float(r["Counter_Value"])
+    for r in csv.DictReader(open(find(path, "counter_collection.csv"))):
+        c = klass(r["Kernel_Name"])
+        if c:
+            a = agg[c]
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
     return {k: (n, v / n) for k, (n, v) in agg.items()}
+
+
+def algorithmic_bytes(c, rows, max_len=300):
+    """SURVEY.md §8(d) / DESIGN.md §4: 1,536 B per key per crop + Qt in / Et out (12 heads x 768 x 2 B each way)."""
+    if c == "lat_attn_cross":
+        return rows * (197 * 1536 + 2 * 12 * 768 * 2)
+    if c == "lat_attn_self":      # context grows 1..299: mean (max_len)/2 keys per launch
+        return rows * (max_len / 2 * 1536 + 2 * 12 * 768 * 2)
+    return None
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--round", default="r01")
+    ap.add_argument("--round", default="r02")
     ap.add_argument("--stats")
     ap.add_argument("--fetch")
     ap.add_argument("--write")
     ap.add_argument("--note", default="")
-    ap.add_argument("--rows", type=int, default=0, help="rows of the merged batch the PMC passes ran")
+    ap.add_argument("--rows", type=int, required=True, help="rows of the internal batches the passes ran")
     a = ap.parse_args()
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
+    classes = {}
     if a.stats:
-        f = [p for p in os.listdir(a.stats) if p.endswith("kernel_stats.csv")][0]
-        shutil.copy(os.path.join(a.stats, f), os.path.join(out, f"{a.round}_kernel_stats.csv"))
+        shutil.copy(find(a.stats, "kernel_stats.csv"), os.path.join(out, f"{a.round}_kernel_stats.csv"))
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(find(a.stats, "kernel_trace.csv"))):
+            c = klass(r["Kernel_Name"])
+            if c:
+                agg[c].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        for c, d in agg.items():
+            classes[c] = {"calls": len(d), "avg_ns": sum(d) / len(d), "min_ns": min(d), "max_ns": max(d)}
+            alg = algorithmic_bytes(c, a.rows)
+            if alg:
+                classes[c]["algorithmic_bytes_per_launch"] = alg
+                classes[c]["achieved_GBps"] = alg / classes[c]["avg_ns"]
+                classes[c]["frac_of_8TBps"] = alg / classes[c]["avg_ns"] / 8000.0
+        json.dump({"note": a.note, "rows": a.rows, "classes": classes}, open(os.path.join(out, f"{a.round}_kernel_classes.json"), "w"), indent=1)
     if a.fetch and a.write:
         fe, wr = pmc(a.fetch), pmc(a.write)
-        res = {"note": a.note, "rows": a.rows, "correction": "traffic_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE reads half of a 16 B/lane stream)",
-               "kernels": {}}
-        for k, (n, v) in sorted(fe.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
-            w = wr.get(k, (0, 0.0))[1]
-            res["kernels"][k] = {"launches": n, "fetch_size_kb_avg": v, "write_size_kb_avg": w,
-                                 "traffic_bytes": (2 * v + w) * 1024}
-        json.dump(res, open(os.path.join(out, f"{a.round}_pmc_traffic.json"), "w"), indent=1)
-    print(os.listdir(out))
+        path = os.path.join(out, f"{a.round}_pmc_traffic.json")
+        res = json.load(open(path)) if os.path.exists(path) else {}
+        res.setdefault("correction", "traffic_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE reads half of a 16 B/lane stream)")
+        res["note"] = a.note
+        by = res.setdefault("by_rows", {}).setdefault(str(a.rows), {})
+        for c, (n, v) in fe.items():
+            w = wr.get(c, (0, 0.0))[1]
+            ent = {"launches": n, "fetch_size_kb_avg": v, "write_size_kb_avg": w, "traffic_bytes_per_launch": (2 * v + w) * 1024}
+            alg = algorithmic_bytes(c, a.rows)
+            if alg:
+                ent["algorithmic_bytes_per_launch"] = alg
+                ent["traffic_over_algorithmic"] = ent["traffic_bytes_per_launch"] / alg
+            by[c] = ent
+        json.dump(res, open(path, "w"), indent=1)
+    print(sorted(os.listdir(out)))
 
 
 if __name__ == "__main__":
