@@ -117,6 +117,8 @@ def main():
     ap.add_argument("--max-batch", type=int, default=8192, help="rows of one internal engine batch: submitted steps are merged up to this")
     ap.add_argument("--queue", type=int, default=0, help="strong-scaling mode: ONE queue of this many crops sharded over the ranks (configs[3]: 10000)")
     ap.add_argument("--cpu-sample", type=int, default=16, help="crops per regime the CPU baseline (oracle) decodes")
+    ap.add_argument("--fp8-attention", action="store_true",
+                    help="opt-in mode of BASELINE configs[4]: e4m3 key/value rows + fp8 MFMA in the decode attention (not the parity configuration)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--only-timed", action="store_true",
@@ -148,7 +150,9 @@ def main():
     spec = dataclasses.replace(DEFAULT_SPEC, max_len=args.max_len)
     weights = synthetic_weights(0)
     args.max_batch = max(args.max_batch, args.batch)
-    eng = Engine(weights, spec, dtype=args.dtype, device=local, max_batch=args.max_batch, lanes=args.lanes)
+    eng = Engine(weights, spec, dtype=args.dtype, device=local, max_batch=args.max_batch, lanes=args.lanes,
+                 flags=128 if args.fp8_attention else 0)
+    dtype_label = args.dtype + ("+fp8attn" if args.fp8_attention else "")
     B, L = args.batch, args.max_len
     strong = args.queue > 0
     if strong:
@@ -321,7 +325,7 @@ def main():
         out = {
             "metric": "manga crops/sec (224x224, max_len=300)", "value": value, "unit": "crops/s", "n_gpus": world,
             "steps": steps_timed, "warmup": args.warmup, "ms_per_step": dt / steps_timed * 1e3, "higher_is_better": True,
-            "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": dtype_label, "data": "synthetic",
             "config": {"workload": workload + f", ViT-B/16 encoder + 2-layer BERT decoder, greedy decode max_len={L} (T={T} steps, EOS never fires "
                                    "with synthetic weights)",
                        "global_batch": world * B, "queue": args.queue or None, "engine_max_batch": args.max_batch, "lanes": args.lanes, "max_len": L,

@@ -51,6 +51,10 @@ enum {
     MOCR_FLAG_CLASSIC_ATTENTION = 1 << 3, /* bf16: projected K/V caches instead of the latent (absorbed) decode attention */
     MOCR_FLAG_NO_FUSED_ARGMAX = 1 << 4,   /* always write the logits and take the argmax in the token kernel */
     MOCR_FLAG_NO_FUSED_QQT = 1 << 5,      /* latent attention: query and absorbed query as two GEMM launches even for fat batches */
+    MOCR_FLAG_FP8_ATTENTION = 1 << 7,     /* bf16 engines, opt-in (BASELINE configs[4]): the latent decode attention reads its
+                                           * key/value rows as OCP e4m3 (768 B per key instead of 1,536 B, static per-source
+                                           * scales) and runs both products on fp8 MFMA, softmax in fp32.  NOT the parity
+                                           * configuration: its accuracy is reported by tests/test_gpu_fp8_attention.py */
     MOCR_FLAG_LATENT_ALWAYS = 1 << 6      /* bf16: latent attention for every batch size (default: batches of <= 256 rows take the
                                            * classic projected-K/V kernels, whose grid - one block per (row, head) - has half the
                                            * step latency there: 50 instead of 80 ms for 64 crops) */
@@ -182,6 +186,12 @@ int mocr_op_enc_attention(mocr_engine* e, const void* d_qkv, void* d_ctx, int32_
  * sequences, context length len for every row; d_out [n,16,768] = softmax(qt . x^T) x per head. */
 int mocr_op_latent_attention(mocr_engine* e, const void* d_qt, const void* d_x, void* d_out, int32_t n, int32_t len,
                              int64_t x_batch_stride);
+
+/* fp8 attention (MOCR_FLAG_FP8_ATTENTION) operators: d_x bf16 [n_elems] -> d_x8 e4m3 [n_elems] = e4m3(x * inv_sx);
+ * and the latent attention on e4m3 key rows (768 B per key, x = x8 * sx): d_qt [n,16,768] bf16, d_out [n,16,768] bf16. */
+int mocr_op_quant_fp8(mocr_engine* e, const void* d_x, void* d_x8, int64_t n_elems, float inv_sx);
+int mocr_op_latent_attention_fp8(mocr_engine* e, const void* d_qt, const void* d_x8, void* d_out, int32_t n, int32_t len,
+                                 int64_t x_batch_stride_bytes, float sx);
 
 /* Fused query path of the latent attention (bf16 engines): d_x [rows_pad,768] bf16 (rows_pad = n rounded up to 128),
  * d_wq [768,768] bf16, d_bq [768] f32, d_wkT [768,768] bf16 (row n, column 64h+k = Wk_h[k][n]/8), d_qt [rows_pad,16,768] bf16:

@@ -95,6 +95,13 @@ template <typename T> __device__ __forceinline__ float gelu_for(float x) {
     if constexpr (sizeof(T) == 2) return gelu_fast(x); else return gelu_erf(x);
 }
 
+// four floats -> four OCP e4m3 bytes (v_cvt_pk_fp8_f32: round to nearest even); callers keep |v| <= 448
+__device__ __forceinline__ unsigned pack4_fp8(float a, float b, float c, float d) {
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    return (unsigned)w;
+}
+
 // Async global -> LDS copy, 16 bytes per lane.  `lds_wave_base` must be wave-uniform: the
 // hardware writes lane i's 16 bytes at lds_wave_base + 16*i (cdna_hip_programming.md §5).
 __device__ __forceinline__ void glds16(const void* gsrc_lane, void* lds_wave_base) {

@@ -29,6 +29,7 @@
 #include "kernels_decode.h"
 #include "kernels_gemm.h"
 #include "kernels_latent.h"
+#include "kernels_latent8.h"
 #include "preprocess.h"
 #include "kernels_qqt.h"
 #include "kernels_misc.h"
@@ -72,6 +73,9 @@ struct Weights {
     void* wv = nullptr; float* bv = nullptr;
     float* lut = nullptr;
     float* zero_bias = nullptr;
+    // fp8 attention (MOCR_FLAG_FP8_ATTENTION): static e4m3 scales of the key/value sources (x = x8 * sx)
+    float sx_enc = 1.f;                 // encoder output = LayerNorm_f
+    std::vector<float> sx_self;         // per decoder layer: its input rows (embedding LayerNorm / previous layer's LayerNorm 3)
 };
 
 struct ProfRec { int kid; hipEvent_t e0, e1; double flops, bytes; };
@@ -100,6 +104,8 @@ struct LaneCtx {
     int* h_pinned = nullptr;                        // [4] pinned: early-exit flags
     // latent attention (bf16): q [Bp,768], Qt / Et [Bp,16,768], per-layer input rows [layers][Bp][max_len][768]
     void *q_t = nullptr, *qt = nullptr, *et = nullptr, *xcache = nullptr;
+    // fp8 attention: e4m3 copies of the encoder output [Mp][768] and of the per-layer input rows [layers][Bp][max_len][768]
+    uint8_t *enc8 = nullptr, *x8cache = nullptr;
 };
 
 // One recognise request of <= max_batch crops.
@@ -133,6 +139,7 @@ struct mocr_engine : LaneCtx {
     bool poisoned = false;          // a HIP call failed: HIP errors are sticky, so every later call is refused
     bool committed = false;
     int gen_max_len = 0;            // generate(max_length) of the device-buffer submissions (mocr_set_generate_max_length)
+    bool fp8attn = false;           // latent attention on e4m3 key/value rows + fp8 MFMA (MOCR_FLAG_FP8_ATTENTION, opt-in)
     bool latent = false;            // bf16 engines: latent (absorbed) decode attention ...
     int classic_rows = 0;           // ... for batches of more than this many rows; smaller ones use the classic kernels
     int Bc = 0;                     // rows the classic K/V buffers are sized for
@@ -497,16 +504,25 @@ void dec_add_ln(mocr_engine* e, int nslab, int N, const float* bias, const float
                 float* out_f32, void* out_t, int rows, bool gelu, int cache_layer = -1) {
     ProfScope ps(e, "dec_add_ln", 0, (double)rows * N * 4 * (nslab + 3));
     T* cache = nullptr;
+    uint8_t* cache8 = nullptr;
+    float inv8 = 0.f;
     const long long cstride = (long long)e->cfg.max_len * e->D;
-    if (cache_layer >= 0) cache = reinterpret_cast<T*>(e->xcache) + (size_t)cache_layer * e->Bp * cstride;
+    if (cache_layer >= 0) {
+        if (e->fp8attn) {
+            cache8 = e->x8cache + (size_t)cache_layer * e->Bp * cstride;
+            inv8 = 1.0f / e->w.sx_self[cache_layer];
+        } else {
+            cache = reinterpret_cast<T*>(e->xcache) + (size_t)cache_layer * e->Bp * cstride;
+        }
+    }
     if (gelu)
         hipLaunchKernelGGL((dec_add_ln_kernel<T, 768, true>), dim3(rows), dim3(192), 0, e->stream, e->slabs, nslab,
                            (long long)e->Bp * N, bias, resid, g, b, out_f32, reinterpret_cast<T*>(out_t), rows, e->cfg.ln_eps,
-                           cache, cstride, (const int*)e->step);
+                           cache, cstride, (const int*)e->step, cache8, inv8);
     else
         hipLaunchKernelGGL((dec_add_ln_kernel<T, 768, false>), dim3(rows), dim3(192), 0, e->stream, e->slabs, nslab,
                            (long long)e->Bp * N, bias, resid, g, b, out_f32, reinterpret_cast<T*>(out_t), rows, e->cfg.ln_eps,
-                           cache, cstride, (const int*)e->step);
+                           cache, cstride, (const int*)e->step, cache8, inv8);
     HIPCHECK(hipGetLastError());
 }
 
@@ -524,10 +540,12 @@ template <typename T, bool FIRST>
 void dec_token(mocr_engine* e, const DecState& st, int nslab, int n, int ncand = 0) {
     auto& w = e->w;
     ProfScope ps(e, FIRST ? "dec_token_first" : "dec_token", 0, FIRST ? 0.0 : (double)n * e->V * 4 * nslab);
+    const bool lat = e->use_latent(n);
     hipLaunchKernelGGL((dec_token_kernel<T, 768, FIRST>), dim3(n), dim3(256), 0, e->stream, e->slabs, nslab,
                        (long long)e->Bp * e->V, w.bv, e->V, st, w.word, w.type0, w.posd, w.embg, w.embb, e->x_f32,
-                       reinterpret_cast<T*>(e->x_t), e->cfg.ln_eps, e->use_latent(n) ? reinterpret_cast<T*>(e->xcache) : nullptr,
-                       (long long)e->cfg.max_len * e->D, ncand ? e->cand_val : nullptr, ncand ? e->cand_idx : nullptr, ncand);
+                       reinterpret_cast<T*>(e->x_t), e->cfg.ln_eps, (lat && !e->fp8attn) ? reinterpret_cast<T*>(e->xcache) : nullptr,
+                       (long long)e->cfg.max_len * e->D, ncand ? e->cand_val : nullptr, ncand ? e->cand_idx : nullptr, ncand,
+                       (lat && e->fp8attn) ? e->x8cache : nullptr, (lat && e->fp8attn) ? 1.0f / w.sx_self[0] : 0.f);
     HIPCHECK(hipGetLastError());
 }
 
@@ -576,6 +594,31 @@ void dec_attn(mocr_engine* e, int layer, int nslab, int n, const float* bias, in
 // Latent attention of n rows: Qt [n,16,768] x keys (self: cached layer-input rows; cross: encoder
 // output) -> Et [n,16,768].  bytes: the X rows streamed once (1,536 B per key).
 void latent_attn(mocr_engine* e, bool self, int layer, int n, int approx_len) {
+    static const int lat_blocks8 = env_int("MOCR_LAT_BLOCKS", 256);
+    if (e->fp8attn) {
+        Latent8Params p{};
+        p.qt = reinterpret_cast<const bf16_t*>(e->qt);
+        p.out = reinterpret_cast<bf16_t*>(e->et);
+        p.heads = e->H;
+        p.rows = n;
+        if (self) {
+            p.x8 = e->x8cache + (size_t)layer * e->Bp * e->cfg.max_len * e->D;
+            p.x_batch_stride = (long long)e->cfg.max_len * e->D;
+            p.step = e->step;
+            p.sx = e->w.sx_self[layer];
+        } else {
+            p.x8 = e->enc8;
+            p.x_batch_stride = (long long)e->S * e->D;
+            p.fixed_len = e->S;
+            p.sx = e->w.sx_enc;
+        }
+        ProfScope ps(e, self ? "lat8_attn_self" : "lat8_attn_cross", 4.0 * n * 16 * approx_len * e->D,
+                     (double)n * approx_len * e->D + 2.0 * n * e->H * e->D * 2);     // e4m3 keys + Qt in + Et out (12 heads, bf16)
+        if (self) hipLaunchKernelGGL(latent_attn_fp8_kernel<true>, dim3(std::min(n, lat_blocks8)), dim3(256), LAT8_LDS, e->stream, p);
+        else hipLaunchKernelGGL(latent_attn_fp8_kernel<false>, dim3(std::min(n, lat_blocks8)), dim3(256), LAT8_LDS, e->stream, p);
+        HIPCHECK(hipGetLastError());
+        return;
+    }
     LatentParams p{};
     p.qt = reinterpret_cast<const bf16_t*>(e->qt);
     p.out = reinterpret_cast<bf16_t*>(e->et);
@@ -701,6 +744,15 @@ void run_cross_kv(mocr_engine* e, int n) {
             EPI_BIAS, ET, 1);
 }
 
+// fp8 attention: the batch's encoder output as e4m3 rows (static scale), once per batch
+void quantize_enc(mocr_engine* e, int n) {
+    const long long n16 = (long long)n * e->S * e->D / 16;
+    ProfScope ps(e, "quant_enc_fp8", 0, (double)n * e->S * e->D * 3);
+    hipLaunchKernelGGL(quant_rows_fp8_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, e->stream,
+                       reinterpret_cast<const bf16_t*>(e->ENC), e->enc8, n16, 1.0f / e->w.sx_enc);
+    HIPCHECK(hipGetLastError());
+}
+
 // Raise the dynamic-LDS limit of every kernel that needs it (done once, outside any capture).
 template <typename T> void init_kernel_attrs() {
     constexpr int l128 = 2 * (128 + 128) * 128, l64 = 2 * (64 + 64) * 128;
@@ -738,6 +790,8 @@ template <typename T> void init_kernel_attrs() {
     set_max_lds(gemm256_kernel<EPI_BIAS_F32>, l256);
     set_max_lds(latent_attn_kernel<true>, LAT_LDS);
     set_max_lds(latent_attn_kernel<false>, LAT_LDS);
+    set_max_lds(latent_attn_fp8_kernel<true>, LAT8_LDS);
+    set_max_lds(latent_attn_fp8_kernel<false>, LAT8_LDS);
 }
 
 // `steps` consecutive greedy steps captured once and replayed: every per-step value (position,
@@ -827,6 +881,7 @@ void start_batch(mocr_engine* e, Lane& L) {
     }
     run_encoder<T>(e, e->d_in, L.n);
     if (!e->use_latent(L.np)) run_cross_kv<T>(e, L.n);
+    else if (e->fp8attn) quantize_enc(e, L.n);
     // rows read pad_id (= 0) beyond what the loop writes
     HIPCHECK(hipMemsetAsync(e->ids, 0, (size_t)L.np * e->cfg.max_len * sizeof(int), e->stream));
     // The decode steps run on np >= n rows (graph_rows): the padding rows are born finished, emit pad_id and read
@@ -1033,6 +1088,21 @@ void commit_weights(mocr_engine* e) {
     }
     w.lnfg = up.f32(up.get("encoder.layernorm.weight", {D}));
     w.lnfb = up.f32(up.get("encoder.layernorm.bias", {D}));
+    // Static e4m3 scale of a LayerNorm output: |gamma_k z_k + beta_k| <= max|gamma| sqrt(D - 1) + max|beta| for ANY input
+    // (a normalised vector's element is at most sqrt(D - 1)), mapped onto e4m3's largest finite value 448.
+    auto ln_scale = [&](const std::string& gname, const std::string& bname) {
+        float gm = 0.f, bm = 0.f;
+        for (float v : up.get(gname, {D})) gm = std::max(gm, std::fabs(v));
+        for (float v : up.get(bname, {D})) bm = std::max(bm, std::fabs(v));
+        return (gm * std::sqrt((float)(D - 1)) + bm) / 448.0f;
+    };
+    w.sx_enc = ln_scale("encoder.layernorm.weight", "encoder.layernorm.bias");
+    w.sx_self.assign(c.dec_layers, 1.f);
+    w.sx_self[0] = ln_scale("decoder.bert.embeddings.LayerNorm.weight", "decoder.bert.embeddings.LayerNorm.bias");
+    for (int l = 1; l < c.dec_layers; ++l) {
+        const std::string pp = "decoder.bert.encoder.layer." + std::to_string(l - 1) + ".output.LayerNorm.";
+        w.sx_self[l] = ln_scale(pp + "weight", pp + "bias");
+    }
     const std::string d = "decoder.bert.";
     w.word = up.f32(up.get(d + "embeddings.word_embeddings.weight", {V, D}));
     w.posd = up.f32(up.get(d + "embeddings.position_embeddings.weight", {(int64_t)c.max_pos, D}));
@@ -1132,7 +1202,11 @@ void allocate_lane(mocr_engine* e, int lane_id) {
         e->q_t = e->dalloc<char>(Bp * D * esz);
         e->qt = e->dalloc<char>(Bp * 16 * D * esz);
         e->et = e->dalloc<char>(Bp * 16 * D * esz);
-        e->xcache = e->dalloc<char>(((size_t)c.dec_layers * Bp * c.max_len + 64) * D * esz);
+        if (!e->fp8attn) e->xcache = e->dalloc<char>(((size_t)c.dec_layers * Bp * c.max_len + 64) * D * esz);
+        else {
+            e->x8cache = e->dalloc<uint8_t>(((size_t)c.dec_layers * Bp * c.max_len + 64) * D);
+            e->enc8 = e->dalloc<uint8_t>((Mp + 64) * D);
+        }
     }
     if (e->Bc > 0) {      // classic K/V: the whole engine (fp32 / MOCR_FLAG_CLASSIC_ATTENTION) or its small batches
         const size_t Mc = (size_t)round_up(e->Bc * e->S, 256) + 256;
@@ -1156,6 +1230,7 @@ void allocate_lane(mocr_engine* e, int lane_id) {
 void allocate_lanes(mocr_engine* e) {
     compute_geometry(e);
     e->latent = e->cfg.dtype == MOCR_BF16 && !(e->cfg.flags & MOCR_FLAG_CLASSIC_ATTENTION);
+    e->fp8attn = e->latent && (e->cfg.flags & MOCR_FLAG_FP8_ATTENTION);
     // Small batches of a latent engine take the classic kernels: the persistent latent kernel walks a sequence's key
     // tiles serially on ONE CU (~20 us per call whatever the batch), the classic one spreads a row over 12 blocks.
     // Measured (r01, 300 tokens): 8 rows 36 vs 73 ms, 64 rows 50 vs 80 ms, 256 rows 111 vs 116 ms.
@@ -1648,6 +1723,7 @@ int mocr_decode_logits(mocr_engine* e, const void* d_gray, int32_t n, const int3
             using T_ = decltype(tag);
             run_encoder<T_>(e, g, n);
             if (!e->use_latent(n)) run_cross_kv<T_>(e, n);
+            else if (e->fp8attn) quantize_enc(e, n);
             run_decode_forced<T_>(e, n, e->forced, T, e->logits_dbg);
         });
         HIPCHECK(hipMemcpyAsync(h_logits, e->logits_dbg, lcount * 4, hipMemcpyDeviceToHost, e->stream));
@@ -1723,6 +1799,40 @@ int mocr_op_latent_attention(mocr_engine* e, const void* d_qt, const void* d_x, 
             }
             fprintf(stderr, "[lat stamps, cycles] wait+issue %llu  S %llu  exchange %llu  softmax %llu  PX %llu  other %llu\n", h[0], h[1], h[2], h[3], h[4], h[5]);
         }
+    });
+}
+
+int mocr_op_quant_fp8(mocr_engine* e, const void* d_x, void* d_x8, int64_t n_elems, float inv_sx) {
+    return guarded(e, [&] {
+        std::lock_guard<std::mutex> lk(e->mu);
+        HIPCHECK(hipSetDevice(e->cfg.device));
+        drive(e);
+        e->bind(0);
+        if (!d_x || !d_x8 || n_elems < 16 || n_elems % 16) throw ArgError{"bad argument (n_elems must be a positive multiple of 16)", MOCR_ERR_ARG};
+        const long long n16 = n_elems / 16;
+        hipLaunchKernelGGL(quant_rows_fp8_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, e->stream,
+                           reinterpret_cast<const bf16_t*>(d_x), reinterpret_cast<uint8_t*>(d_x8), n16, inv_sx);
+        HIPCHECK(hipGetLastError());
+        HIPCHECK(hipStreamSynchronize(e->stream));
+    });
+}
+
+int mocr_op_latent_attention_fp8(mocr_engine* e, const void* d_qt, const void* d_x8, void* d_out, int32_t n, int32_t len,
+                                 int64_t x_batch_stride_bytes, float sx) {
+    return guarded(e, [&] {
+        std::lock_guard<std::mutex> lk(e->mu);
+        HIPCHECK(hipSetDevice(e->cfg.device));
+        drive(e);
+        e->bind(0);
+        if (e->cfg.dtype != MOCR_BF16 || !d_qt || !d_x8 || !d_out || n < 1 || len < 1 || !(sx > 0.f)) throw ArgError{"bad argument", MOCR_ERR_ARG};
+        Latent8Params p{};
+        p.qt = reinterpret_cast<const bf16_t*>(d_qt); p.x8 = reinterpret_cast<const uint8_t*>(d_x8);
+        p.out = reinterpret_cast<bf16_t*>(d_out); p.x_batch_stride = x_batch_stride_bytes; p.fixed_len = len; p.heads = e->H;
+        p.rows = n; p.sx = sx;
+        ProfScope ps(e, "op_latent8", 0, (double)n * len * 768);
+        hipLaunchKernelGGL(latent_attn_fp8_kernel<false>, dim3(std::min((int)n, env_int("MOCR_LAT_BLOCKS", 256))), dim3(256), LAT8_LDS, e->stream, p);
+        HIPCHECK(hipGetLastError());
+        HIPCHECK(hipStreamSynchronize(e->stream));
     });
 }
 

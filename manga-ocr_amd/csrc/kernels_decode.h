@@ -16,7 +16,8 @@ __global__ __launch_bounds__(D / 4) void dec_add_ln_kernel(const float* __restri
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            float* __restrict__ out_f32, T* __restrict__ out_t, int rows, float eps,
                                                            T* __restrict__ cache = nullptr, long long cache_batch_stride = 0,
-                                                           const int* __restrict__ step = nullptr) {
+                                                           const int* __restrict__ step = nullptr, uint8_t* __restrict__ cache8 = nullptr,
+                                                           float inv_sx8 = 0.f) {
     constexpr int NW = D / 256;                      // waves per block
     __shared__ float s_red[2][NW];
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -68,6 +69,10 @@ __global__ __launch_bounds__(D / 4) void dec_add_ln_kernel(const float* __restri
     elem<T>::st4(out_t + (size_t)row * D + c, o);
     // latent attention: this row is also the key/value source of position step[row] for the next layer
     if (cache) elem<T>::st4(cache + (size_t)row * cache_batch_stride + (size_t)step[row] * D + c, o);
+    // fp8 attention mode: the same row as e4m3 bytes with the cache's static scale (kernels_latent8.h)
+    if (cache8)
+        *reinterpret_cast<unsigned*>(cache8 + (size_t)row * cache_batch_stride + (size_t)step[row] * D + c) =
+            pack4_fp8(o[0] * inv_sx8, o[1] * inv_sx8, o[2] * inv_sx8, o[3] * inv_sx8);
 }
 
 // out T = gelu( sum_s slab_s + bias )   (the decoder FFN's intermediate activation)
@@ -126,7 +131,8 @@ __global__ __launch_bounds__(256) void dec_token_kernel(const float* __restrict_
                                                         T* __restrict__ x_t, float eps, T* __restrict__ cache = nullptr,
                                                         long long cache_batch_stride = 0,
                                                         const float* __restrict__ cand_val = nullptr,
-                                                        const int* __restrict__ cand_idx = nullptr, int ncand = 0) {
+                                                        const int* __restrict__ cand_idx = nullptr, int ncand = 0,
+                                                        uint8_t* __restrict__ cache8 = nullptr, float inv_sx8 = 0.f) {
     __shared__ float s_val[4];
     __shared__ int s_idx[4];
     __shared__ float s_red[4];
@@ -231,5 +237,6 @@ __global__ __launch_bounds__(256) void dec_token_kernel(const float* __restrict_
         x_f32[(size_t)b * D + d] = o;
         elem<T>::st(x_t + (size_t)b * D + d, o);
         if (cache) elem<T>::st(cache + (size_t)b * cache_batch_stride + (size_t)ps * D + d, o);   // layer-0 key/value source
+        if (cache8) cache8[(size_t)b * cache_batch_stride + (size_t)ps * D + d] = (uint8_t)(pack4_fp8(o * inv_sx8, 0.f, 0.f, 0.f) & 0xff);
     }
 }

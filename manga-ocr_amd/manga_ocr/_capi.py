@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "_lib", "libmocr_hip.so")
 MOCR_OK = 0
 MOCR_F32, MOCR_BF16 = 0, 1
 FLAG_SIMPLE_ATTENTION, FLAG_NO_GRAPH, FLAG_NO_EARLY_EXIT, FLAG_CLASSIC_ATTENTION = 1, 2, 4, 8
-FLAG_NO_FUSED_ARGMAX, FLAG_NO_FUSED_QQT, FLAG_LATENT_ALWAYS = 16, 32, 64
+FLAG_NO_FUSED_ARGMAX, FLAG_NO_FUSED_QQT, FLAG_LATENT_ALWAYS, FLAG_FP8_ATTENTION = 16, 32, 64, 128
 EPI_SLAB, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_PATCH, EPI_BIAS_F32 = range(6)
 
 
@@ -67,6 +67,8 @@ SYMBOLS = {
     "mocr_op_layernorm": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32]),
     "mocr_op_enc_attention": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32]),
     "mocr_op_latent_attention": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int64]),
+    "mocr_op_quant_fp8": (C.c_int, [_P, _P, _P, C.c_int64, C.c_float]),
+    "mocr_op_latent_attention_fp8": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int64, C.c_float]),
     "mocr_op_qqt": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32]),
     "mocr_profile_enable": (C.c_int, [_P, C.c_int32]),
     "mocr_profile_reset": (C.c_int, [_P]),

@@ -212,6 +212,12 @@ class Engine:
     def op_latent_attention(self, d_qt, d_x, d_out, n, length, x_batch_stride) -> None:
         self._check(self.lib.mocr_op_latent_attention(self._h, _ptr(d_qt), _ptr(d_x), _ptr(d_out), n, length, x_batch_stride))
 
+    def op_quant_fp8(self, d_x, d_x8, n_elems: int, inv_sx: float) -> None:
+        self._check(self.lib.mocr_op_quant_fp8(self._h, _ptr(d_x), _ptr(d_x8), n_elems, inv_sx))
+
+    def op_latent_attention_fp8(self, d_qt, d_x8, d_out, n, length, x_batch_stride_bytes, sx) -> None:
+        self._check(self.lib.mocr_op_latent_attention_fp8(self._h, _ptr(d_qt), _ptr(d_x8), _ptr(d_out), n, length, x_batch_stride_bytes, sx))
+
     # ------------------------------------------------------------------ per-kernel timing
     def op_qqt(self, d_x, d_wq, d_bq, d_wkT, d_qt, n: int) -> None:
         self._check(self.lib.mocr_op_qqt(self._h, _ptr(d_x), _ptr(d_wq), _ptr(d_bq), _ptr(d_wkT), _ptr(d_qt), n))
