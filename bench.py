@@ -125,6 +125,12 @@ def main():
                     help="warm-up + timed region only (the rocprofv3 passes: every launch in the trace then belongs to the timed shape)")
     args = ap.parse_args()
 
+    # ONE JSON line on stdout and nothing else: libraries write banners there (RCCL prints its version block on the
+    # first communicator), so stdout is pointed at stderr until the line is ready
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     from manga_ocr.engine import Engine
     from manga_ocr.shard import shard_bounds
@@ -337,10 +343,16 @@ def main():
             "isolated_step_ms": isolated, "regime_T32": t32, "encoder_only": enc_only,
             "roofline": roof, "cpu_baseline": cpu, "kernels": kernels[:24],
         }
-        print(json.dumps(out), flush=True)
+        line = json.dumps(out)
+    else:
+        line = None
     if use_dist:
         dist.destroy_process_group()
     eng.close()
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
+    if line is not None:
+        print(line, flush=True)
 
 
 if __name__ == "__main__":

@@ -11,8 +11,9 @@
 //     query is quantised IN the kernel once per row (per-head scale from the head's amax: one cross-wave max);
 //     probabilities are quantised as e4m3(256 p) (p in [0, 1]: 256 p stays below 448 and is a normal number down
 //     to p = 6e-5); the softmax itself is fp32.
-//   * tile = 32 keys x 768 B = 24 KiB, FIVE ring stages (120 KiB): four tiles (96 KiB) in flight per CU.  The finished
-//     row is staged in an LDS area of its own: unlike in the bf16 kernel a ring slot must never hold anything but e4m3
+//   * tile = 32 keys x 768 B = 24 KiB, FIVE ring stages (120 KiB); an iteration consumes TWO tiles (64 keys), so the
+//     barriers and LDS round trips between the phases are paid once per 64 keys.  The finished
+//     row is staged outside the ring: unlike in the bf16 kernel a ring slot must never hold anything but e4m3
 //     bytes, because the key rows a trimmed last tile leaves untouched are multiplied (by probability 0) and a stale
 //     0x7F / 0xFF byte is an e4m3 NaN.
 //     LDS image: 8-byte chunk c of key row r at chunk c ^ 2 (r & 15) - conflict-free both for the ds_read_b64 row
@@ -29,8 +30,9 @@
 #define LAT8_TILE_BYTES (LAT_TK * LAT_D)      // 24 KiB
 #define LAT8_NST 5
 #define LAT8_PIECES (LAT8_TILE_BYTES / 1024)  // 24 DMA pieces of 1 KiB per tile
-#define LAT8_STG (12 * LAT_OUT_HS)            // output staging: 12 heads x (768 bf16 + 16 B)
-#define LAT8_LDS (LAT8_NST * LAT8_TILE_BYTES + 4 * 16 * 32 * 4 + 1024 + LAT8_STG)
+#define LAT8_STG (12 * LAT_OUT_HS)            // output staging: 12 heads x (768 bf16 + 16 B) = 18,624 B, shared with the
+                                              // score / probability scratch (16 KiB + 1 KiB), which is idle at a row's end
+#define LAT8_LDS (LAT8_NST * LAT8_TILE_BYTES + 19 * 1024 + 512)
 #define LAT8_PSCALE 256.0f
 
 struct Latent8Params {
@@ -92,10 +94,11 @@ __global__ __launch_bounds__(256, 1) void latent_attn_fp8_kernel(Latent8Params p
     const long long P_xstride = p.x_batch_stride;
     const int P_rows = p.rows, P_heads = p.heads;
     const float P_sx = p.sx;
-    float* sS = reinterpret_cast<float*>(smem + LAT8_NST * LAT8_TILE_BYTES);       // [4][16][32] partial scores
-    uint8_t* sP = reinterpret_cast<uint8_t*>(sS + 4 * 16 * 32);                     // [16][32] e4m3 probabilities (512 B)
-    float* sAl = reinterpret_cast<float*>(sP + 512);                                // [16] alpha, [16] row sums, [4][16] query amax
-    char* const stg = reinterpret_cast<char*>(sP) + 1024;                           // finished row: 12 heads x LAT_OUT_HS
+    float* sS = reinterpret_cast<float*>(smem + LAT8_NST * LAT8_TILE_BYTES);       // [4][16][64] partial scores (16 KiB)
+    uint8_t* sP = reinterpret_cast<uint8_t*>(sS + 4 * 16 * 64);                     // [16][64] e4m3 probabilities (1 KiB)
+    char* const stg = reinterpret_cast<char*>(sS);                                  // finished row: 12 heads x LAT_OUT_HS (over sS / sP)
+    float* sAl = reinterpret_cast<float*>(reinterpret_cast<char*>(sS) + 19 * 1024); // [16] alpha, [16] row sums, [4][16] query amax
+    static_assert(LAT8_STG <= 19 * 1024, "staging fits the scratch");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     const int nblk = gridDim.x;
@@ -156,7 +159,9 @@ __global__ __launch_bounds__(256, 1) void latent_attn_fp8_kernel(Latent8Params p
         }                                                                                                         \
     } while (0)
     // a trimmed last tile leaves key rows of its slot untouched: they must hold finite e4m3 bytes (0 x NaN = NaN)
-    if (np_last < LAT8_PIECES) {
+    // (and a row's odd last tile reads - with probability 0 - the ring's next slot, which at the start of a block may
+    // never have been written)
+    if (np_last < LAT8_PIECES || (cnt & 1)) {
 #pragma unroll 4
         for (int i = tid; i < LAT8_NST * LAT8_TILE_BYTES / 16; i += 256)
             *reinterpret_cast<uint4*>(smem + (size_t)i * 16) = make_uint4(0, 0, 0, 0);
@@ -165,6 +170,7 @@ __global__ __launch_bounds__(256, 1) void latent_attn_fp8_kernel(Latent8Params p
 #pragma unroll
     for (int k = 0; k < LAT8_NST - 1; ++k) ISSUE_NEXT8();
     int slot = 0;
+    bool prev_pair = false;              // the previous iteration consumed two ring slots (so two are free to refill)
 
     while (cr < P_rows) {
         bf16x8 qn[6];
@@ -226,73 +232,92 @@ __global__ __launch_bounds__(256, 1) void latent_attn_fp8_kernel(Latent8Params p
             for (int r = 0; r < 4; ++r) cacc[dt][r] = 0.f;
         float m_run = -INFINITY, l_run = 0.f;
 
-        for (int t = 0; t < cnt; ++t) {
+        // Two key tiles (64 keys) per iteration: the three block-wide barriers and the LDS round trips between the phases
+        // (partial scores, probabilities) are paid once per 64 keys.  With 32 keys per iteration the kernel was bound
+        // by exactly that chain (r02: 2.25 us per 24 KiB tile = 3.05 TB/s, only 1.2x the bf16 kernel's rate for half
+        // the bytes).  A row's odd last tile runs with the ring's next slot as its partner: those keys lie beyond L, get
+        // probability 0, and the slot holds e4m3 bytes of SOME tile (finite), so it is only read, not consumed.
+        for (int t = 0; t < cnt; t += 2) {
+            const bool pair = t + 1 < cnt;
+            const int slot2 = slot + 1 == LAT8_NST ? 0 : slot + 1;
             if (wave < 3) {
-                const int mk = slot == 0 ? mk0 : slot == 1 ? mk1 : slot == 2 ? mk2 : slot == 3 ? mk3 : mk4;
+                const int ws = pair ? slot2 : slot;        // the younger of the tiles this iteration consumes
+                const int mk = ws == 0 ? mk0 : ws == 1 ? mk1 : ws == 2 ? mk2 : ws == 3 ? mk3 : mk4;
                 wait_vm_newer(issued - mk);
             }
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            ISSUE_NEXT8();                        // refills the slot every wave has finished reading
-            const unsigned xt_a = smem_base + (unsigned)(slot * LAT8_TILE_BYTES);
-            slot = slot + 1 == LAT8_NST ? 0 : slot + 1;
-            // ---- partial scores over this wave's 192 dims
-            f32x4 sacc[2];
+            ISSUE_NEXT8();                        // refill what the previous iteration consumed: every wave is past its reads
+            if (t == 0 ? prev_pair : true) ISSUE_NEXT8();
+            const unsigned xt_a = smem_base + (unsigned)(slot * LAT8_TILE_BYTES), xt_b = smem_base + (unsigned)(slot2 * LAT8_TILE_BYTES);
+            slot = pair ? (slot2 + 1 == LAT8_NST ? 0 : slot2 + 1) : slot2;
+            // ---- partial scores over this wave's 192 dims: four 16-key sub-tiles
+            f32x4 sacc[4];
             {
                 unsigned sa[12];
-                unsigned long long xs[12];
+                unsigned long long xa[12], xb[12];
 #pragma unroll
                 for (int k = 0; k < 12; ++k) sa[k] = xt_a + s_off[k];
-                lds_read12_b64(xs, sa);
+                lds_read12_b64(xa, sa);
+#pragma unroll
+                for (int k = 0; k < 12; ++k) sa[k] = xt_b + s_off[k];
+                lds_read12_b64(xb, sa);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) sacc[j][r] = 0.f;
 #pragma unroll
-                    for (int s = 0; s < 6; ++s)
-                        sacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8((long)q8[s], (long)xs[6 * j + s], sacc[j], 0, 0, 0);
+                for (int s = 0; s < 6; ++s) {       // four independent accumulation chains interleaved
+                    sacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8((long)q8[s], (long)xa[s], sacc[0], 0, 0, 0);
+                    sacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8((long)q8[s], (long)xa[6 + s], sacc[1], 0, 0, 0);
+                    sacc[2] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8((long)q8[s], (long)xb[s], sacc[2], 0, 0, 0);
+                    sacc[3] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8((long)q8[s], (long)xb[6 + s], sacc[3], 0, 0, 0);
                 }
             }
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) sS[(wave * 16 + 4 * g + r) * 32 + 16 * j + l15] = sacc[j][r];
+                for (int r = 0; r < 4; ++r) sS[(wave * 16 + 4 * g + r) * 64 + 16 * j + l15] = sacc[j][r];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            float v0, v1;
+            float v[4];
             {
-                const int o = (4 * g + wave) * 32 + l15;
-                v0 = ((sS[o] + sS[512 + o]) + (sS[1024 + o] + sS[1536 + o])) * sc;
-                v1 = ((sS[o + 16] + sS[512 + o + 16]) + (sS[1024 + o + 16] + sS[1536 + o + 16])) * sc;
+                const int o = (4 * g + wave) * 64 + l15;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[j] = ((sS[o + 16 * j] + sS[1024 + o + 16 * j]) + (sS[2048 + o + 16 * j] + sS[3072 + o + 16 * j])) * sc;
+                    if (t * LAT_TK + 16 * j + l15 >= L) v[j] = -INFINITY;
+                }
             }
-            if (t * LAT_TK + l15 >= L) v0 = -INFINITY;
-            if (t * LAT_TK + 16 + l15 >= L) v1 = -INFINITY;
             {
-                float mx = v0 > v1 ? v0 : v1;
+                float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
                 mx = row16_max(mx);
-                const float mn = mx > m_run ? mx : m_run;
+                const float mn = mx > m_run ? mx : m_run;          // finite: the first tile of the pair has a valid key
                 const float al = __expf(m_run - mn);
-                const float p0 = __expf(v0 - mn), p1 = __expf(v1 - mn);
+                const float p0 = __expf(v[0] - mn), p1 = __expf(v[1] - mn), p2 = __expf(v[2] - mn), p3 = __expf(v[3] - mn);
                 // e4m3(256 p): one byte each (v_cvt_pk_fp8_f32 rounds to nearest even).  The row sum is taken over the
                 // QUANTISED weights, so the weights that multiply X still sum to exactly 1 after the division by l.
-                const unsigned pk = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(p0 * LAT8_PSCALE, p1 * LAT8_PSCALE, 0, false);
-                const float pq = (__builtin_amdgcn_cvt_f32_fp8((int)pk, 0) + __builtin_amdgcn_cvt_f32_fp8((int)pk, 1)) * (1.0f / LAT8_PSCALE);
+                const unsigned pk = pack4_fp8(p0 * LAT8_PSCALE, p1 * LAT8_PSCALE, p2 * LAT8_PSCALE, p3 * LAT8_PSCALE);
+                const float pq = ((__builtin_amdgcn_cvt_f32_fp8((int)pk, 0) + __builtin_amdgcn_cvt_f32_fp8((int)pk, 1)) +
+                                  (__builtin_amdgcn_cvt_f32_fp8((int)pk, 2) + __builtin_amdgcn_cvt_f32_fp8((int)pk, 3))) * (1.0f / LAT8_PSCALE);
                 l_run = l_run * al + row16_sum(pq);
                 m_run = mn;
-                uint8_t* pw = sP + (4 * g + wave) * 32 + l15;
+                uint8_t* pw = sP + (4 * g + wave) * 64 + l15;
                 pw[0] = (uint8_t)(pk & 0xff);
                 pw[16] = (uint8_t)((pk >> 8) & 0xff);
+                pw[32] = (uint8_t)((pk >> 16) & 0xff);
+                pw[48] = (uint8_t)(pk >> 24);
                 if (l15 == 0) sAl[4 * g + wave] = al;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             uint4 al4;
-            unsigned long long pa;       // A operand: P8[head = lane & 15][key = 8 g .. 8 g + 7]
-            asm volatile("ds_read_b128 %0, %2\n\tds_read_b64 %1, %3\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&v"(al4), "=&v"(pa) : "v"(lds_addr(sAl) + 16 * g), "v"(lds_addr(sP) + l15 * 32 + 8 * g) : "memory");
+            unsigned long long pa, pb;       // A operands: P8[head = lane & 15][key = 8 g .. 8 g + 7] of the two tiles
+            asm volatile("ds_read_b128 %0, %3\n\tds_read_b64 %1, %4\n\tds_read_b64 %2, %4 offset:32\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(al4), "=&v"(pa), "=&v"(pb) : "v"(lds_addr(sAl) + 16 * g), "v"(lds_addr(sP) + l15 * 64 + 8 * g) : "memory");
             __builtin_amdgcn_sched_barrier(0);
             {
                 const float a0 = __uint_as_float(al4.x), a1 = __uint_as_float(al4.y), a2 = __uint_as_float(al4.z), a3 = __uint_as_float(al4.w);
@@ -303,18 +328,23 @@ __global__ __launch_bounds__(256, 1) void latent_attn_fp8_kernel(Latent8Params p
                     }
                 }
             }
-            // ---- C[head][d] += P8[head][key] X8[key][d] over this wave's 192 columns: one transposed read per d-tile
+            // ---- C[head][d] += P8[head][key] X8[key][d] over this wave's 192 columns: one transposed read per d-tile and key tile
             {
                 unsigned ad[12];
-                unsigned long long xr[12];
+                unsigned long long xr[12], xq[12];
 #pragma unroll
                 for (int k = 0; k < 12; ++k) ad[k] = xt_a + tr_off[k];
                 tr8_read12(xr, ad);
+#pragma unroll
+                for (int k = 0; k < 12; ++k) ad[k] = xt_b + tr_off[k];
+                tr8_read12(xq, ad);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int k = 0; k < 12; ++k)
-                    cacc[k] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8((long)pa, (long)xr[k], cacc[k], 0, 0, 0);
+                for (int k = 0; k < 12; ++k) cacc[k] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8((long)pa, (long)xr[k], cacc[k], 0, 0, 0);
+#pragma unroll
+                for (int k = 0; k < 12; ++k) cacc[k] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8((long)pb, (long)xq[k], cacc[k], 0, 0, 0);
             }
+            prev_pair = pair;
         }
         // ---- finish the row: normalise (1 / l, the probability scale 256 and the key scale sx), stage, store
         if (l15 == 0) sAl[16 + 4 * g + wave] = l_run;

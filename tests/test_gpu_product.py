@@ -205,3 +205,29 @@ def test_default_sized_drop_in_reaches_the_device_resident_rate():
         assert dt <= 2.0 * best + 0.05
     finally:
         m.close()
+
+
+def test_main_process_dispatcher_with_the_real_engine_and_rccl_in_a_child_process():
+    """manga_ocr/multi.py with its DEFAULT factory and the nccl (= RCCL) backend: the parent never touches the GPU, a
+    fresh child process builds the HIP engine, decodes the shard, runs the all-gather and hands the rows back.  One GPU
+    here, so the world is one rank - the code path (spawn, process group on the device, shared-memory hand-over) is the
+    one MangaOcr(devices=[0..7]) takes; the sharding itself is covered with gloo in tests/test_multi_dispatch.py."""
+    from manga_ocr.multi import MultiGpuEngine
+    gray = crops(123, 6)
+    rgb = np.random.RandomState(5).randint(0, 256, size=(3, 100, 140, 3), dtype=np.uint8)
+    eng = MultiGpuEngine([0], factory_args=dict(synthetic_seed=0, dtype="bf16", max_batch=16, lanes=1))
+    try:
+        ids, lens = eng.recognize_images(list(gray) + list(rgb))
+        pages = [np.random.RandomState(6).randint(0, 256, size=(300, 300, 3), dtype=np.uint8)]
+        rids, rlens = eng.recognize_regions(pages, [(0, 10, 10, 100, 80), (0, 0, 0, 1, 1)])
+    finally:
+        eng.close()
+    ref = engine("bf16", max_batch=16, auto_path=True)
+    want, wlens = ref.recognize_images(list(gray) + list(rgb))
+    np.testing.assert_array_equal(ids, want)
+    np.testing.assert_array_equal(lens, wlens)
+    wr, wl = ref.recognize_regions(pages, [(0, 10, 10, 100, 80), (0, 0, 0, 1, 1)])
+    np.testing.assert_array_equal(rids, wr)
+    np.testing.assert_array_equal(rlens, wl)
+    assert rlens[1] == 0
+    report("MultiGpuEngine([0]) (child process, RCCL group of one) == in-process engine: ids identical")
