@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 BF16_LOGIT_TOL = 3e-2     # max |logit - oracle logit| accepted, teacher-forced (measured: 1.2e-2 .. 1.4e-2)
-BF16_GAP_TOL = 5e-2       # a first divergence is accepted only where the reference's own top-2 margin is below this
+BF16_GAP_TOL = 2.5e-2     # a first divergence is accepted only where the reference's own top-2 margin is below this (measured: <= 1.02e-2)
 
 
 @pytest.fixture(scope="module")
