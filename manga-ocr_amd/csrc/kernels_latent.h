@@ -165,9 +165,10 @@ __device__ __forceinline__ void wait_vm_newer(int newer) {
 // tile image) with pc < np.  A full tile is np = 48 pieces (16 DMA instructions per DMA wave); a sequence's last tile
 // asks only for the pieces that hold its valid keys (src_off: this lane's 16 source offsets).  The branch is
 // wave-uniform; the caller adds lat_pieces_of(np, w) to its load count.
+template <int I0 = 0, int I1 = 16>
 __device__ __forceinline__ void lat_stage(const char* src, char* dst, const unsigned (&src_off)[16], int w, int np) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
+    for (int i = I0; i < I1; ++i)
         if (w + 3 * i < np) glds16(src + src_off[i], dst + (w + 3 * i) * 1024);
 }
 __device__ __forceinline__ int lat_pieces_of(int np, int w) { return (np - w + 2) / 3; }   // #i in 0..15 with w+3i < np (np <= 48)
@@ -274,6 +275,38 @@ __global__ __launch_bounds__(256, 1) void latent_attn_kernel(LatentParams p) {
             if (++it == cnt) { ir += nblk; it = 0; }                                                              \
         }                                                                                                         \
     } while (0)
+    // The same request spread over the three phases of an iteration (r02): a DMA wave's 16 pieces cost it 60-185 cycles
+    // of issue each, and issued as one burst behind the top barrier they delayed the wave's own score phase - and with
+    // it the block's next barrier.  The slot being refilled is read by nobody during the whole iteration, so pieces
+    // 0-5 go out behind the top barrier, 6-10 behind the score barrier (the softmax phase is short and latency-bound)
+    // and 11-15 behind the probability barrier; the bookkeeping (load count, slot mark, ring position) is done once,
+    // with the last part.  Cross launch at 2560 rows: 193.6 -> 182.7 us.  (Moving ALL the DMA issue to two extra
+    // loader waves - a six-wave block - was also built and measured: 183.9 us, i.e. nothing more; removed.)
+    const char* is_src = nullptr;
+    char* is_dst = nullptr;
+    int is_np = 0;
+#define ISSUE_BEGIN()                                                                                             \
+    do {                                                                                                          \
+        is_np = 0;                                                                                                \
+        if (ir < P_rows) {                                                                                        \
+            is_np = it == cnt - 1 ? np_last : 48;                                                                 \
+            is_src = reinterpret_cast<const char*>(P_x + (size_t)ir * P_xstride) + (size_t)it * LAT_TILE_BYTES;    \
+            is_dst = smem + islot * LAT_TILE_BYTES;                                                               \
+        }                                                                                                         \
+    } while (0)
+#define ISSUE_PART(I0, I1)                                                                                        \
+    do {                                                                                                          \
+        if (is_np > 0 && wave < 3) lat_stage<I0, I1>(is_src, is_dst, src_off, wave, is_np);                       \
+    } while (0)
+#define ISSUE_END()                                                                                               \
+    do {                                                                                                          \
+        if (is_np > 0) {                                                                                          \
+            if (wave < 3) issued += lat_pieces_of(is_np, wave);                                                   \
+            if (islot == 0) mk0 = issued; else if (islot == 1) mk1 = issued; else mk2 = issued;                   \
+            islot = islot + 1 == LAT_NST ? 0 : islot + 1;                                                         \
+            if (++it == cnt) { ir += nblk; it = 0; }                                                              \
+        }                                                                                                         \
+    } while (0)
     // pieces of a sequence's last tile that hold valid keys (rows are 96 chunks, pieces 64 chunks)
     const int np_last = (96 * (L - (cnt - 1) * LAT_TK) + 63) >> 6;
     // The key rows such a trimmed request leaves alone keep whatever the slot held before: older X rows
@@ -311,7 +344,8 @@ __global__ __launch_bounds__(256, 1) void latent_attn_kernel(LatentParams p) {
             if (wave < 3) wait_vm_newer(issued - (slot == 0 ? mk0 : slot == 1 ? mk1 : mk2));
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            ISSUE_NEXT();                         // refills the slot every wave has finished reading
+            ISSUE_BEGIN();                        // refills the slot every wave has finished reading, in three parts
+            ISSUE_PART(0, 6);
             const char* xt = smem + slot * LAT_TILE_BYTES;
             slot = slot + 1 == LAT_NST ? 0 : slot + 1;
             STAMP(0)   // wait + barrier + DMA issue
@@ -350,6 +384,7 @@ __global__ __launch_bounds__(256, 1) void latent_attn_kernel(LatentParams p) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            ISSUE_PART(6, 11);
             // ---- online softmax, split over the waves: wave w owns accumulator register r = w, i.e. heads
             // {4g + w}; a head's 32 keys sit on the 16 lanes of its group x 2 sub-tiles
             float v0, v1;
@@ -377,6 +412,8 @@ __global__ __launch_bounds__(256, 1) void latent_attn_kernel(LatentParams p) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            ISSUE_PART(11, 16);
+            ISSUE_END();
             // alpha[4g..4g+3] and the A operand P[head = lane&15][key = 8*g + jj] through inline asm: a plain
             // LDS load here gets a compiler s_waitcnt vmcnt(0) in front (DMA-alias conservatism)
             uint4 ap[2];
@@ -499,6 +536,9 @@ __global__ __launch_bounds__(256, 1) void latent_attn_kernel(LatentParams p) {
         for (int k = 0; k < 6; ++k) P_dbg[k] = tsum[k];
 #endif
 #undef STAMP
+#undef ISSUE_BEGIN
+#undef ISSUE_PART
+#undef ISSUE_END
 #undef ISSUE_NEXT
 #undef Q_PTR
 }
