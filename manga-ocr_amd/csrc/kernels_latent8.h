@@ -50,9 +50,10 @@ struct Latent8Params {
 // byte offset of logical 8-byte chunk c (0..95) of key row r inside a tile image
 __device__ __forceinline__ int lat8_off(int r, int c) { return r * LAT_D + ((c ^ ((r & 15) << 1)) << 3); }
 
+template <int I0 = 0, int I1 = 8>
 __device__ __forceinline__ void lat8_stage(const char* src, char* dst, const unsigned (&src_off)[8], int w, int np) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = I0; i < I1; ++i)
         if (w + 3 * i < np) glds16(src + src_off[i], dst + (w + 3 * i) * 1024);
 }
 
@@ -158,6 +159,34 @@ __global__ __launch_bounds__(256, 1) void latent_attn_fp8_kernel(Latent8Params p
             if (++it == cnt) { ir += nblk; it = 0; }                                                              \
         }                                                                                                         \
     } while (0)
+    // the second request of an iteration goes out in two halves, behind the score and the probability barrier (see
+    // latent_attn_kernel: the DMA issue of a burst delays the issuing wave's own phase)
+    const char* is_src = nullptr;
+    char* is_dst = nullptr;
+    int is_np = 0;
+#define ISSUE_BEGIN8()                                                                                            \
+    do {                                                                                                          \
+        is_np = 0;                                                                                                \
+        if (ir < P_rows) {                                                                                        \
+            is_np = it == cnt - 1 ? np_last : LAT8_PIECES;                                                        \
+            is_src = reinterpret_cast<const char*>(P_x) + (size_t)ir * P_xstride + (size_t)it * LAT8_TILE_BYTES;   \
+            is_dst = smem + islot * LAT8_TILE_BYTES;                                                              \
+        }                                                                                                         \
+    } while (0)
+#define ISSUE_PART8(I0, I1)                                                                                       \
+    do {                                                                                                          \
+        if (is_np > 0 && wave < 3) lat8_stage<I0, I1>(is_src, is_dst, src_off, wave, is_np);                      \
+    } while (0)
+#define ISSUE_END8()                                                                                              \
+    do {                                                                                                          \
+        if (is_np > 0) {                                                                                          \
+            if (wave < 3) issued += lat_pieces_of(is_np, wave);                                                   \
+            switch (islot) { case 0: mk0 = issued; break; case 1: mk1 = issued; break; case 2: mk2 = issued; break;  \
+                             case 3: mk3 = issued; break; default: mk4 = issued; }                                \
+            islot = islot + 1 == LAT8_NST ? 0 : islot + 1;                                                        \
+            if (++it == cnt) { ir += nblk; it = 0; }                                                              \
+        }                                                                                                         \
+    } while (0)
     // a trimmed last tile leaves key rows of its slot untouched: they must hold finite e4m3 bytes (0 x NaN = NaN)
     // (and a row's odd last tile reads - with probability 0 - the ring's next slot, which at the start of a block may
     // never have been written)
@@ -248,7 +277,9 @@ __global__ __launch_bounds__(256, 1) void latent_attn_fp8_kernel(Latent8Params p
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             ISSUE_NEXT8();                        // refill what the previous iteration consumed: every wave is past its reads
-            if (t == 0 ? prev_pair : true) ISSUE_NEXT8();
+            const bool second = t == 0 ? prev_pair : true;
+            is_np = 0;
+            if (second) ISSUE_BEGIN8();
             const unsigned xt_a = smem_base + (unsigned)(slot * LAT8_TILE_BYTES), xt_b = smem_base + (unsigned)(slot2 * LAT8_TILE_BYTES);
             slot = pair ? (slot2 + 1 == LAT8_NST ? 0 : slot2 + 1) : slot2;
             // ---- partial scores over this wave's 192 dims: four 16-key sub-tiles
@@ -282,6 +313,7 @@ __global__ __launch_bounds__(256, 1) void latent_attn_fp8_kernel(Latent8Params p
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            ISSUE_PART8(0, 4);
             float v[4];
             {
                 const int o = (4 * g + wave) * 64 + l15;
@@ -314,6 +346,8 @@ __global__ __launch_bounds__(256, 1) void latent_attn_fp8_kernel(Latent8Params p
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            ISSUE_PART8(4, 8);
+            ISSUE_END8();
             uint4 al4;
             unsigned long long pa, pb;       // A operands: P8[head = lane & 15][key = 8 g .. 8 g + 7] of the two tiles
             asm volatile("ds_read_b128 %0, %3\n\tds_read_b64 %1, %4\n\tds_read_b64 %2, %4 offset:32\n\ts_waitcnt lgkmcnt(0)"
@@ -403,6 +437,9 @@ __global__ __launch_bounds__(256, 1) void latent_attn_fp8_kernel(Latent8Params p
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #undef ISSUE_NEXT8
+#undef ISSUE_BEGIN8
+#undef ISSUE_PART8
+#undef ISSUE_END8
 #undef Q_PTR
 }
 
