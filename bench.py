@@ -116,7 +116,7 @@ def main():
     ap.add_argument("--lanes", type=int, default=2, help="internal batches the engine keeps in flight (streams + workspaces)")
     ap.add_argument("--max-batch", type=int, default=8192, help="rows of one internal engine batch: submitted steps are merged up to this")
     ap.add_argument("--queue", type=int, default=0, help="strong-scaling mode: ONE queue of this many crops sharded over the ranks (configs[3]: 10000)")
-    ap.add_argument("--cpu-sample", type=int, default=16, help="crops per regime the CPU baseline (oracle) decodes")
+    ap.add_argument("--cpu-sample", type=int, default=48, help="crops per regime the CPU baseline (oracle) decodes: ~15-20 s of CPU work in all")
     ap.add_argument("--fp8-attention", action="store_true",
                     help="opt-in mode of BASELINE configs[4]: e4m3 key/value rows + fp8 MFMA in the decode attention (not the parity configuration)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
