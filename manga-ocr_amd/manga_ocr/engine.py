@@ -124,10 +124,11 @@ class Engine:
             if not pix_ok:
                 a = np.ascontiguousarray(a)
             keep.append(a)
-            descs[i].data = a.ctypes.data
-            descs[i].height, descs[i].width = a.shape[0], a.shape[1]
-            descs[i].row_stride = a.strides[0]
-            descs[i].channels = _capi.CHANNELS_BGR if (bgr and ch == 3) else ch
+            d = descs[i]
+            d.data = a.__array_interface__["data"][0]        # (a.ctypes.data builds a ctypes object per call: 10x slower)
+            d.height, d.width = a.shape[0], a.shape[1]
+            d.row_stride = a.strides[0]
+            d.channels = _capi.CHANNELS_BGR if (bgr and ch == 3) else ch
         return descs, keep
 
     def recognize_images(self, images, bgr: bool = False) -> Tuple[np.ndarray, np.ndarray]:

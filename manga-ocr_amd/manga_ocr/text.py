@@ -92,6 +92,23 @@ class Vocab:
         self._arr = np.array(self.tokens + ["[UNK]"], dtype=object)       # last slot: ids outside the table
         self._special = np.zeros(len(self.tokens) + 1, dtype=bool)
         self._special[list(self.special_ids)] = True
+        # fast path of ids_to_text: post_process removes ALL whitespace, so the decode's `" ".join(...).replace(" ##", "")`
+        # reduces to concatenating the tokens with the "##" of every non-first word piece dropped and the whitespace inside
+        # tokens removed; both per-token forms are precomputed (checked against the plain composition in the CPU tests)
+        nows = ["".join(t.split()) for t in self.tokens] + ["[UNK]"]
+        self._first = np.array(nows, dtype=object)
+        self._rest = np.array(["".join(t[2:].split()) if t.startswith("##") else n for t, n in zip(self.tokens + ["[UNK]"], nows)], dtype=object)
+        self._plain = not any((" ##" in t) or (t != "##" and t.endswith(" ") ) for t in self.tokens)
+        # ... and with post_process's character-wise steps applied per token where they commute with concatenation:
+        # "…" -> "..." and the half -> full-width translation of everything except '.' and '･' (the dot-run rule must
+        # still see the ASCII dot and must not see a '・' that comes from a half-width '･'); tokens with a (semi-)voiced
+        # mark combine with their neighbour and send the row down the plain path
+        def pre(t):
+            t = t.replace("…", "...")
+            return "".join(ch if ch in ".･" else _h2z_tables(ch, ascii=True, digit=True) for ch in t)
+        self._first_pre = np.array([pre(t) for t in self._first.tolist()], dtype=object)
+        self._rest_pre = np.array([pre(t) for t in self._rest.tolist()], dtype=object)
+        self._mark = np.array([("ﾞ" in t) or ("ﾟ" in t) for t in self.tokens] + [False], dtype=bool)
 
     @classmethod
     def from_file(cls, path: str) -> "Vocab":
@@ -118,7 +135,29 @@ class Vocab:
 
 
 def ids_to_text(vocab: Vocab, ids: Iterable[int]) -> str:
-    return post_process(vocab.decode(ids, skip_special_tokens=True))
+    """tokenizer.decode(ids, skip_special_tokens=True) followed by post_process."""
+    if not vocab._plain:           # a vocabulary with whitespace-bearing tokens that could fake a " ##" seam: plain composition
+        return post_process(vocab.decode(ids, skip_special_tokens=True))
+    import numpy as np
+    a = np.asarray(list(ids) if not hasattr(ids, "__len__") else ids, dtype=np.int64).ravel()
+    a = np.where((a >= 0) & (a < len(vocab.tokens)), a, len(vocab.tokens))
+    a = a[~vocab._special[a]]
+    if a.size == 0:
+        return ""
+    if _jaconv is not None or vocab._mark[a].any():
+        text = vocab._first[a[0]] + "".join(vocab._rest[a[1:]].tolist())
+        text = text.replace("…", "...")
+        if "・" in text or ".." in text:
+            text = re.sub("[・.]{2,}", lambda m: (m.end() - m.start()) * ".", text)
+        return h2z(text, ascii=True, digit=True)
+    text = vocab._first_pre[a[0]] + "".join(vocab._rest_pre[a[1:]].tolist())
+    if "・" in text or ".." in text:
+        text = re.sub("[・.]{2,}", lambda m: (m.end() - m.start()) * ".", text)
+    if "." in text:
+        text = text.replace(".", _H2Z_A["."])
+    if "･" in text:
+        text = text.replace("･", _H2Z_K["･"])
+    return text
 
 
 def find_vocab(model_dir: Optional[str]) -> Optional[str]:

@@ -126,3 +126,19 @@ def test_vocab_decode_skips_special_tokens_and_joins_wordpieces():
     assert text.ids_to_text(v, [2, 5, 6, 7, 8, 3, 0]) == "日本語ａ"
     s = text.Vocab.synthetic(6144)
     assert len(s) == 6144 and text.ids_to_text(s, [2, 5, 6, 3]) == "一丁"
+
+
+def test_fast_ids_to_text_equals_decode_then_post_process():
+    """ids_to_text's precomputed per-token path must be the plain composition tokenizer.decode -> post_process for every
+    row: word pieces ('##'), whitespace inside tokens, '…', dot runs across token seams, half-width kana with and without
+    (semi-)voiced marks, ids outside the table."""
+    from hf_dir import vocab_tokens
+    edge = text.Vocab(["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]", ".", "･", "・", "…", "ｶ", "ﾞ", "##.", "a", "1", "##ｶ", "ﾊ", "ﾟ",
+                       "あ", "　", "##", "x y"] + [chr(0x4E00 + i) for i in range(60)])
+    for v in (text.Vocab.synthetic(6144), text.Vocab(vocab_tokens()), edge):
+        rs = np.random.RandomState(len(v))
+        ids = rs.randint(-2, len(v) + 2, size=(300, 120))
+        ids[:, :60] = rs.randint(0, min(40, len(v)), size=(300, 60))
+        for row in ids:
+            assert text.ids_to_text(v, row) == text.post_process(v.decode(row))
+        assert text.ids_to_text(v, []) == "" and text.ids_to_text(v, [2, 3, 0]) == ""
