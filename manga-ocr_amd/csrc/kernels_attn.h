@@ -103,36 +103,65 @@ __global__ __launch_bounds__(256, 2) void enc_attn_mfma_kernel(const bf16_t* __r
     const int D = H * DH;
     const bf16_t* base = qkv + (size_t)b * ENC_S * ld_qkv + h * DH;
 
-    // ---- stage K (swizzled rows) and V^T; zero the padding keys 197..223(227)
-    for (int i = tid; i < ENC_SP * 8; i += 256) {
-        const int s = i >> 3, c = i & 7;
-        uint4 kv = make_uint4(0, 0, 0, 0);
-        if (s < ENC_S) kv = *reinterpret_cast<const uint4*>(base + (size_t)s * ld_qkv + D + c * 8);
-        *reinterpret_cast<uint4*>(sK + s * 128 + ((c ^ ((s >> 1) & 7)) << 4)) = kv;
-    }
-    // V^T: a thread takes the same 8 d-values of TWO adjacent keys and writes (key, key+1) pairs as dwords
-    for (int i = tid; i < (ENC_VT_LD / 2) * 8; i += 256) {
-        const int s = (i >> 3) * 2, c = i & 7;
-        uint4 v0 = make_uint4(0, 0, 0, 0), v1 = make_uint4(0, 0, 0, 0);
-        if (s < ENC_S) v0 = *reinterpret_cast<const uint4*>(base + (size_t)s * ld_qkv + 2 * D + c * 8);
-        if (s + 1 < ENC_S) v1 = *reinterpret_cast<const uint4*>(base + (size_t)(s + 1) * ld_qkv + 2 * D + c * 8);
-        const unsigned w0[4] = {v0.x, v0.y, v0.z, v0.w}, w1[4] = {v1.x, v1.y, v1.z, v1.w};
+    // ---- the queries of this wave's two tiles, requested before anything else (r02: they used to be loaded at the head of
+    // each tile, a full global-load latency in front of the tile's first MFMA)
+    bf16x8 qpre[2][4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const unsigned lo = (w0[e >> 1] >> (16 * (e & 1))) & 0xffffu, hi = (w1[e >> 1] >> (16 * (e & 1))) & 0xffffu;
-            *reinterpret_cast<unsigned*>(sVt + (c * 8 + e) * ENC_VT_LD + s) = lo | (hi << 16);
+    for (int ti = 0; ti < 2; ++ti) {
+        const int qq = (wave + 4 * ti) * 32 + r32;
+        const int qc = qq < ENC_S ? qq : ENC_S - 1;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            qpre[ti][s] = *reinterpret_cast<const bf16x8*>(base + (size_t)qc * ld_qkv + s * 16 + hh * 8);
+    }
+    // ---- stage K (swizzled rows) and V^T; zero the padding keys 197..223(227).  ALL global loads of a thread are issued
+    // before the first LDS store (r02): left as a rolled loop the seven + four load -> store round trips ran one
+    // after the other, a global-load latency each (126 -> 97 us per 3072-block launch at batch 256)
+    {
+        uint4 kv[7];
+#pragma unroll
+        for (int it = 0; it < 7; ++it) {
+            const int i = tid + 256 * it, s_ = i >> 3, c = i & 7;
+            kv[it] = make_uint4(0, 0, 0, 0);
+            if (s_ < ENC_S) kv[it] = *reinterpret_cast<const uint4*>(base + (size_t)s_ * ld_qkv + D + c * 8);
+        }
+        uint4 v0[4], v1[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int i = tid + 256 * it, s_ = (i >> 3) * 2, c = i & 7;
+            v0[it] = make_uint4(0, 0, 0, 0); v1[it] = make_uint4(0, 0, 0, 0);
+            if (i < (ENC_VT_LD / 2) * 8) {
+                if (s_ < ENC_S) v0[it] = *reinterpret_cast<const uint4*>(base + (size_t)s_ * ld_qkv + 2 * D + c * 8);
+                if (s_ + 1 < ENC_S) v1[it] = *reinterpret_cast<const uint4*>(base + (size_t)(s_ + 1) * ld_qkv + 2 * D + c * 8);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 7; ++it) {
+            const int i = tid + 256 * it, s_ = i >> 3, c = i & 7;
+            *reinterpret_cast<uint4*>(sK + s_ * 128 + ((c ^ ((s_ >> 1) & 7)) << 4)) = kv[it];
+        }
+        // V^T: a thread takes the same 8 d-values of TWO adjacent keys and writes (key, key+1) pairs as dwords
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int i = tid + 256 * it, s_ = (i >> 3) * 2, c = i & 7;
+            if (i < (ENC_VT_LD / 2) * 8) {
+                const unsigned w0[4] = {v0[it].x, v0[it].y, v0[it].z, v0[it].w}, w1[4] = {v1[it].x, v1[it].y, v1[it].z, v1[it].w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const unsigned lo = (w0[e >> 1] >> (16 * (e & 1))) & 0xffffu, hi = (w1[e >> 1] >> (16 * (e & 1))) & 0xffffu;
+                    *reinterpret_cast<unsigned*>(sVt + (c * 8 + e) * ENC_VT_LD + s_) = lo | (hi << 16);
+                }
+            }
         }
     }
     __syncthreads();
 
     for (int qt = wave; qt < ENC_SP / 32; qt += 4) {
-        const int q = qt * 32 + r32;
-        const int qc = q < ENC_S ? q : ENC_S - 1;   // clamp: padded queries are computed, not stored
+        const int q = qt * 32 + r32;                // (padded queries are computed from a clamped row, not stored)
         // B operand of S^T = K.Q^T : lane holds Q[q][16s + 8hh .. +7]
         bf16x8 qf[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-            qf[s] = *reinterpret_cast<const bf16x8*>(base + (size_t)qc * ld_qkv + s * 16 + hh * 8);
+        for (int s = 0; s < 4; ++s) qf[s] = qt == wave ? qpre[0][s] : qpre[1][s];
         f32x16 st[7];
 #pragma unroll
         for (int kt = 0; kt < 7; ++kt) {
