@@ -540,7 +540,8 @@ __global__ __launch_bounds__(256, 1) void gemm256_kernel(GemmParams p) {
 template <int EPI>
 __device__ __forceinline__ void gemm_wide_epilogue(const GemmParams& p, f32x4 (&acc)[4][8], float (&bias)[4][4], int em0, int en0, int nb,
                                                    int wm, int wn, int l15, int g4, bool guard) {
-    using T __attribute__((unused)) = bf16_t;
+    using T = bf16_t;
+    (void)sizeof(T);
     {
         {
             // residual rows: inline-asm loads, software-pipelined one row group ahead of the stores (no LDS-DMA is in

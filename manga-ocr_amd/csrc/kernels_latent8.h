@@ -264,7 +264,9 @@ __global__ __launch_bounds__(256, 1) void latent_attn_fp8_kernel(Latent8Params p
         // Two key tiles (64 keys) per iteration: the three block-wide barriers and the LDS round trips between the phases
         // (partial scores, probabilities) are paid once per 64 keys.  With 32 keys per iteration the kernel was bound
         // by exactly that chain (r02: 2.25 us per 24 KiB tile = 3.05 TB/s, only 1.2x the bf16 kernel's rate for half
-        // the bytes).  A row's odd last tile runs with the ring's next slot as its partner: those keys lie beyond L, get
+        // the bytes; 1.72 us per tile now).  Also built and measured: the software-pipelined single-tile loop (P.X of
+        // tile t beside the scores of tile t+1, two barriers per tile): 2.15 us per tile - slower than pairing; the two
+        // cannot be combined in a five-slot ring (four tiles resident + two in flight).  A row's odd last tile runs with the ring's next slot as its partner: those keys lie beyond L, get
         // probability 0, and the slot holds e4m3 bytes of SOME tile (finite), so it is only read, not consumed.
         for (int t = 0; t < cnt; t += 2) {
             const bool pair = t + 1 < cnt;
