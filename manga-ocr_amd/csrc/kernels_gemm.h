@@ -632,7 +632,6 @@ __device__ __forceinline__ void gemm_wide_epilogue(const GemmParams& p, f32x4 (&
 // instructions than the in-flight LDS-DMA, which is not safe on this part (see kernels_qqt.h).  Removed.)
 template <int EPI, int WN>
 __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void gemm_wide_kernel(GemmParams p) {
-    using T = bf16_t;
     constexpr int BM = 256, BN = 64 * WN, NST = 3, NW = 2 * WN;
     constexpr int PA = 16 / NW, PW = (BN / 16) / NW, LPT = PA + PW;   // DMA pieces per wave per K-tile: A rows, W rows
     constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64, STAGE = A_BYTES + B_BYTES;
