@@ -250,7 +250,8 @@ def main():
     # ---- one isolated step (B crops submitted alone, nothing to merge with): the latency a single caller sees
     isolated = {}
     if extras and not light:
-        for b in sorted({64, 256, B}):
+        more = {int(v) for v in os.environ.get("MOCR_BENCH_ISOLATED", "").split(",") if v}      # extra sizes (experiments)
+        for b in sorted({64, 256, B} | more):
             if b > B:
                 continue
             for rep in range(3):                      # the first call captures the decode graphs of this batch size

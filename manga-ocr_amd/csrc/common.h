@@ -102,9 +102,33 @@ __device__ __forceinline__ unsigned pack4_fp8(float a, float b, float c, float d
     return (unsigned)w;
 }
 
+// 16-byte non-temporal global accesses (streams that are written / read once: see the users)
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st16_nt(void* p, uint4 v) {
+    u32x4_t t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    __builtin_nontemporal_store(t, reinterpret_cast<u32x4_t*>(p));
+}
+__device__ __forceinline__ uint4 ld16_nt(const void* p) {
+    const u32x4_t t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+    return make_uint4(t.x, t.y, t.z, t.w);
+}
+
 // Async global -> LDS copy, 16 bytes per lane.  `lds_wave_base` must be wave-uniform: the
 // hardware writes lane i's 16 bytes at lds_wave_base + 16*i (cdna_hip_programming.md §5).
 __device__ __forceinline__ void glds16(const void* gsrc_lane, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+// The same with the non-temporal cache policy (aux = 2, `nt`): for bytes one CU reads once per launch
+// (MI355X_MICROARCH.md, nt-weights row)
+__device__ __forceinline__ void glds16_nt(const void* gsrc_lane, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 2);
+}
+// the latent attention's key stream is such a stream (r02: +2.7 % crops/s at 2560-row batches, -7 % on an isolated
+// 320..1024-row batch); -DMOCR_LAT_NO_NT builds the default-policy form for A/B runs
+#ifdef MOCR_LAT_NO_NT
+#define LAT_GLDS glds16
+#else
+#define LAT_GLDS glds16_nt
+#endif

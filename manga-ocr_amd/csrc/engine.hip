@@ -586,6 +586,11 @@ void dec_attn(mocr_engine* e, int layer, int nslab, int n, const float* bias, in
         p.cross_len = e->S;
     }
     p.ctx = e->ctx_t; p.H = H; p.scale = 0.125f;
+    // K/V of a 64-row batch (2 layers x 197 keys x 3,072 B = 77 MB + the self cache) live in the Infinity Cache between
+    // steps; from about 128 rows they no longer do and the non-temporal policy wins (r02, isolated batch: 256 rows
+    // 100.2 -> 91.2 ms, 128 rows 69.1 -> 67.5 ms, 64 rows 49.8 -> 50.8 ms)
+    static const int nt_rows = env_int("MOCR_ATTN_NT_ROWS", 128);
+    p.nt = n >= nt_rows;
     ProfScope ps(e, SELF ? "dec_attn_self" : "dec_attn_cross", 4.0 * n * H * approx_len * 64,
                  2.0 * n * H * approx_len * 64 * sizeof(T));
     if (SELF) {
@@ -1245,8 +1250,9 @@ void allocate_lanes(mocr_engine* e) {
     e->fp8attn = e->latent && (e->cfg.flags & MOCR_FLAG_FP8_ATTENTION);
     // Small batches of a latent engine take the classic kernels: the persistent latent kernel walks a sequence's key
     // tiles serially on ONE CU (~20 us per call whatever the batch), the classic one spreads a row over 12 blocks.
-    // Measured (r01, 300 tokens): 8 rows 36 vs 73 ms, 64 rows 50 vs 80 ms, 256 rows 111 vs 116 ms.
-    e->classic_rows = !e->latent ? 0 : (e->cfg.flags & MOCR_FLAG_LATENT_ALWAYS) ? 0 : std::min(env_int("MOCR_CLASSIC_ROWS", 256), e->cfg.max_batch);
+    // Measured (r01, 300 tokens): 8 rows 36 vs 73 ms, 64 rows 50 vs 80 ms, 256 rows 111 vs 116 ms; r02, both paths with
+    // non-temporal key loads: 320 rows 116 vs 126 ms, 384 rows 119 vs 129 ms, 448 / 512 rows (one graph shape) 159 vs 148 ms.
+    e->classic_rows = !e->latent ? 0 : (e->cfg.flags & MOCR_FLAG_LATENT_ALWAYS) ? 0 : std::min(env_int("MOCR_CLASSIC_ROWS", 384), e->cfg.max_batch);
     e->Bc = e->latent ? e->classic_rows : e->Bp;
     const int nl = std::max(1, std::min(16, (int)e->cfg.lanes));
     e->lanes.resize(nl);

@@ -265,6 +265,7 @@ struct DecAttnParams {
     int cross_len;           // 197 (cross)
     int H;
     float scale;
+    int nt;                  // stream the K/V rows with the non-temporal policy (batches whose K/V outgrow the Infinity Cache)
 };
 
 // raw 8-element row chunk: 16 B in bf16, 32 B in fp32; loads issue without being consumed
@@ -272,6 +273,11 @@ template <typename T> struct raw8;
 template <> struct raw8<bf16_t> {
     uint4 v;
     __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const uint4*>(p); }
+    __device__ __forceinline__ void load_nt(const bf16_t* p) {      // non-temporal: a key row is read once per launch
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+        v = make_uint4(t.x, t.y, t.z, t.w);
+    }
     __device__ __forceinline__ void unpack(float* o) const {
         o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
         o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
@@ -284,6 +290,7 @@ template <> struct raw8<float> {
     __device__ __forceinline__ void load(const float* p) {
         a = *reinterpret_cast<const float4*>(p); b = *reinterpret_cast<const float4*>(p + 4);
     }
+    __device__ __forceinline__ void load_nt(const float* p) { load(p); }
     __device__ __forceinline__ void unpack(float* o) const {
         o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
     }
@@ -323,7 +330,18 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(DecAttnParams p) {
     // ---- issue every K/V load of this wave (clamped rows are valid addresses and get weight 0)
     raw8<T> kr[NG], vr[NG];
     const int last = Lc > 0 ? Lc - 1 : 0;
-    if (Lc > 0) {
+    if (Lc > 0 && p.nt) {
+#pragma unroll
+        for (int u = 0; u < NG; ++u) {
+            const int key = min(k_begin + 8 * u + g, last);
+            kr[u].load_nt(kb + (size_t)key * p.kv_row_stride);
+        }
+#pragma unroll
+        for (int u = 0; u < NG; ++u) {
+            const int key = min(k_begin + 8 * u + g, last);
+            vr[u].load_nt(vb + (size_t)key * p.kv_row_stride);
+        }
+    } else if (Lc > 0) {
 #pragma unroll
         for (int u = 0; u < NG; ++u) {
             const int key = min(k_begin + 8 * u + g, last);

@@ -813,7 +813,10 @@ __device__ __forceinline__ void gemm_wide2_epilogue_lds(const GemmParams& p, f32
         for (int it = 0; it < 16; ++it) {
             const int row = 32 * wave + 2 * it + rsel;
             const uint4 v = *reinterpret_cast<const uint4*>(smem + row * 512 + ((lc ^ (row & 15)) << 4));
-            if (!guard || m0 + row < p.M) *reinterpret_cast<uint4*>(obase + (size_t)row * p.ldo) = v;
+            // non-temporal: 232 / 310 MB of QKV / FC1 output per layer at batch 256 pass through once; written with the
+            // default policy they evict the weight slices and activations the other CUs are re-reading (r02: QKV 219 -> 201 us,
+            // FC1 370 -> 353 us, and FC2 - which reads that output - 335 -> 327 us)
+            if (!guard || m0 + row < p.M) st16_nt(obase + (size_t)row * p.ldo, v);
         }
     } else {
         static_assert(EPI == EPI_BIAS_RESID, "fp32 residual epilogue");

@@ -169,7 +169,7 @@ template <int I0 = 0, int I1 = 16>
 __device__ __forceinline__ void lat_stage(const char* src, char* dst, const unsigned (&src_off)[16], int w, int np) {
 #pragma unroll
     for (int i = I0; i < I1; ++i)
-        if (w + 3 * i < np) glds16(src + src_off[i], dst + (w + 3 * i) * 1024);
+        if (w + 3 * i < np) LAT_GLDS(src + src_off[i], dst + (w + 3 * i) * 1024);
 }
 __device__ __forceinline__ int lat_pieces_of(int np, int w) { return (np - w + 2) / 3; }   // #i in 0..15 with w+3i < np (np <= 48)
 
@@ -462,6 +462,9 @@ __global__ __launch_bounds__(256, 1) void latent_attn_kernel(LatentParams p) {
             STAMP(4)   // P read + transposed reads + P.X MFMAs
 #else
             (void)xt;
+            ISSUE_PART(6, 11);      // the bare ring: the whole request, no consumer work
+            ISSUE_PART(11, 16);
+            ISSUE_END();
 #endif
         }
         // ---- finish the row: normalise, stage through LDS (two halves of 8 heads x 768 bf16 = 12 KiB,

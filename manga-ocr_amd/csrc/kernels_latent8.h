@@ -54,7 +54,7 @@ template <int I0 = 0, int I1 = 8>
 __device__ __forceinline__ void lat8_stage(const char* src, char* dst, const unsigned (&src_off)[8], int w, int np) {
 #pragma unroll
     for (int i = I0; i < I1; ++i)
-        if (w + 3 * i < np) glds16(src + src_off[i], dst + (w + 3 * i) * 1024);
+        if (w + 3 * i < np) LAT_GLDS(src + src_off[i], dst + (w + 3 * i) * 1024);
 }
 
 __device__ __forceinline__ void lds_read12_b64(unsigned long long* o, const unsigned* a) {

@@ -1,5 +1,5 @@
 """-m gpu: parity of the BENCHMARKED configuration - the bf16 engine on its automatic path (classic projected-K/V
-kernels up to 256 rows, latent attention above), through the C ABI, at BASELINE configs[1] / configs[2] row counts,
+kernels up to 384 rows, latent attention above), through the C ABI, at BASELINE configs[1] / configs[2] row counts,
 max_len 300 - against the reference arithmetic.
 
 What "bit-identical decoded token ids" can mean for a bf16 engine: greedy decoding is a chain of argmax decisions, and
@@ -63,16 +63,18 @@ def test_bf16_auto_path_free_running_ids_against_the_reference(gold, rows):
     # margin below the bf16 noise, so most 299-decision rows meet one
 
 
-def test_bf16_fat_batch_latent_path_free_running_ids(gold):
-    """> 256 rows take the latent attention (the bench's merged batches): 320 rows = the 256 golden crops + 64 repeats."""
-    eng = engine("bf16", max_batch=320, auto_path=True)
+@pytest.mark.parametrize("rows,path", [(320, "classic"), (448, "latent")])
+def test_bf16_fat_batch_free_running_ids(gold, rows, path):
+    """Above configs[2]: 320 rows still take the classic kernels, 448 rows (> 384) the latent attention - the bench's merged
+    batches.  The rows are the 256 golden crops + repeats."""
+    eng = engine("bf16", max_batch=rows, auto_path=True)
     base = crops(777, 256)
-    gray = np.concatenate([base, base[:64]])
+    gray = np.concatenate([base, base[:rows - 256]])
     ids, _ = eng.recognize(gray)
-    want = np.concatenate([gold["ids_seed0"], gold["ids_seed0"][:64]])
-    gaps = np.concatenate([gold["gaps_seed0"], gold["gaps_seed0"][:64]]).astype(np.float32)
-    first_divergences(ids, want, gaps, "bf16 auto path, 320 rows (latent attention), plain weights")
-    np.testing.assert_array_equal(ids[:64], ids[256:])          # a row does not depend on its position in the batch
+    want = np.concatenate([gold["ids_seed0"], gold["ids_seed0"][:rows - 256]])
+    gaps = np.concatenate([gold["gaps_seed0"], gold["gaps_seed0"][:rows - 256]]).astype(np.float32)
+    first_divergences(ids, want, gaps, f"bf16 auto path, {rows} rows ({path} attention), plain weights")
+    np.testing.assert_array_equal(ids[:rows - 256], ids[256:])          # a row does not depend on its position in the batch
 
 
 @pytest.mark.parametrize("name,flags,auto", [("classic", 8, False), ("latent", 0, False), ("auto", 0, True)])

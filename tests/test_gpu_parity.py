@@ -303,14 +303,14 @@ def test_two_lanes_in_flight_are_reproducible():
 
 
 def test_small_batches_take_the_classic_kernels_and_fat_ones_the_latent():
-    """The product engine chooses per batch: <= 256 rows classic (half the step latency at 64), more rows latent.  Same
+    """The product engine chooses per batch: <= 384 rows classic (half the step latency at 64), more rows latent.  Same
     kernels as the engines that are forced one way or the other, so the ids are identical to theirs."""
-    auto = engine("bf16", max_batch=384, auto_path=True)
-    classic = engine("bf16", max_batch=384, flags=8)
-    latent = engine("bf16", max_batch=384)
-    small, fat = crops(92, 8), crops(93, 300)
+    auto = engine("bf16", max_batch=512, auto_path=True)
+    classic = engine("bf16", max_batch=512, flags=8)
+    latent = engine("bf16", max_batch=512)
+    small, fat = crops(92, 8), crops(93, 400)
     np.testing.assert_array_equal(auto.recognize_gray(small, max_len=120)[0], classic.recognize_gray(small, max_len=120)[0])
     np.testing.assert_array_equal(auto.recognize_gray(fat, max_len=60)[0], latent.recognize_gray(fat, max_len=60)[0])
     # and both kinds interleaved on one engine (the K/V caches of the two paths are separate buffers)
     np.testing.assert_array_equal(auto.recognize_gray(small, max_len=120)[0], classic.recognize_gray(small, max_len=120)[0])
-    report("auto path: 8 rows == classic engine, 300 rows == latent engine (ids identical)")
+    report("auto path: 8 rows == classic engine, 400 rows == latent engine (ids identical)")
