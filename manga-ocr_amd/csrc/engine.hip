@@ -967,7 +967,7 @@ bool pump_once(mocr_engine* e) {
             // queue would fit into fewer of them, it is split evenly over the idle lanes as long as every part keeps
             // >= SPLIT_MIN rows: two fat batches in flight overlap each other's latency-bound phases (+6 % at 2 x 2560
             // against 1 x 5120 rows, r02), while below ~1000 rows merging beats overlapping.
-            constexpr long long SPLIT_MIN = 1024;
+            static const long long SPLIT_MIN = env_int("MOCR_SPLIT_MIN", 1024);
             long long rows_pending = 0;
             for (const Job& p : e->pending) rows_pending += p.n;
             int idle = 0;
