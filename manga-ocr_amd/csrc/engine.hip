@@ -854,6 +854,17 @@ void run_decode_forced(mocr_engine* e, int n, const int* forced, int forced_T, f
 // before chunk c is enqueued, so a lane always has work queued while the host looks at a flag, and
 // a batch whose rows have all emitted EOS stops at most one chunk late.
 constexpr int CHUNK = 8;
+// Small batches use shorter chunks: their steps are launch-bound (105-165 us whatever the rows), a batch whose rows have
+// all finished is noticed (c_f + 2) chunks in, and ordinary speech-bubble texts are 10-30 tokens.  Measured (r02,
+// tools/short_text_probe.py, <= 16 rows, every row ending at once): 8-step chunks 3.03 ms, 4-step 2.19 ms, 2-step
+// 1.71 ms, i.e. a 20-token batch 4.9 -> 3.9 ms; long rows are unaffected up to 16 rows (106 tokens alone: 14.4 -> 13.7 ms),
+// while at 64 rows 2-step chunks cost +3 % on 300-token rows and 4-step chunks nothing.  A replay costs the host
+// 10-16 us against >= 210 us of GPU work per chunk.  MOCR_SMALL_CHUNK (with MOCR_SMALL_CHUNK_ROWS): experiments.
+static int chunk_steps(int rows) {
+    static const int forced = env_int("MOCR_SMALL_CHUNK", 0), forced_rows = env_int("MOCR_SMALL_CHUNK_ROWS", 128);
+    if (forced > 0) return rows <= forced_rows ? std::min(forced, CHUNK) : CHUNK;
+    return rows <= 16 ? 2 : rows <= 128 ? 4 : CHUNK;
+}
 
 // Decode graphs are keyed by row count.  Callers submit any n in 1..max_batch (the batcher of MangaOcr, the crop-job
 // queue), so n is rounded up to a coarse grid before it becomes a key: at most ~40 distinct row counts per engine
@@ -933,10 +944,11 @@ void advance(mocr_engine* e, Lane& L) {
     }
     if (L.t >= L.steps) { finish_batch(e, L); return; }
     DecState st = make_state(e, L.max_len, nullptr, 0, nullptr, L.n);
-    const int k = std::min(CHUNK, L.steps - L.t);
+    const int chunk = chunk_steps(L.np);
+    const int k = std::min(chunk, L.steps - L.t);
     const bool use_graph = !e->prof_on && !(e->cfg.flags & MOCR_FLAG_NO_GRAPH);
-    if (use_graph && k == CHUNK) {
-        HIPCHECK(hipGraphLaunch(decode_graph<T>(e, st, L.np, CHUNK, L.t), e->stream));
+    if (use_graph && k == chunk) {
+        HIPCHECK(hipGraphLaunch(decode_graph<T>(e, st, L.np, chunk, L.t), e->stream));
     } else {
         for (int i = 0; i < k; ++i) {
             if (use_graph) HIPCHECK(hipGraphLaunch(decode_graph<T>(e, st, L.np, 1, L.t + i), e->stream));

@@ -165,7 +165,7 @@ def test_graph_cache_is_bounded_and_padding_rows_do_not_leak():
         np.testing.assert_array_equal(ids, full[:n])
         assert (lens == 20).all()
     count = eng.graph_count()
-    # row counts 1..8, 16, 24, 32, 40 = 12 sizes; per size at most (one 8-step graph + one 1-step graph) in the one
+    # row counts 1..8, 16, 24, 32, 40 = 12 sizes; per size at most (one chunk graph + one 1-step graph) in the one
     # context bucket that 20 tokens touch
     assert count <= 12 * 2 and count >= base
     report(f"graph cache after sweeping n = 1..40: {count} graphs (bound 24)")
