@@ -31,6 +31,7 @@
 #include "kernels_gemm.h"
 #include "kernels_latent.h"
 #include "kernels_latent8.h"
+#include "kernels_smallm.h"
 #include "preprocess.h"
 #include "kernels_qqt.h"
 #include "kernels_misc.h"
@@ -99,6 +100,7 @@ struct LaneCtx {
     float* slabs = nullptr; long long slab_cap = 0; // floats
     float* cand_val = nullptr; int* cand_idx = nullptr;   // [Bp][vocab/64] per-tile argmax candidates of the LM head
     float *x_f32 = nullptr, *a_f32 = nullptr, *c_f32 = nullptr;
+    float* ln_stats = nullptr;                      // small-batch path: (mean, rstd) per row of the three pre-LayerNorm sums, [3][Bp][2]
     void *x_t = nullptr, *a_t = nullptr, *c_t = nullptr, *ctx_t = nullptr, *h_t = nullptr, *z_t = nullptr;
     int *ids = nullptr, *step = nullptr, *finished = nullptr, *len = nullptr, *n_unf = nullptr;
     int* forced = nullptr; float* logits_dbg = nullptr; size_t forced_cap = 0, logits_cap = 0;
@@ -145,6 +147,8 @@ struct mocr_engine : LaneCtx {
     int classic_rows = 0;           // ... for batches of more than this many rows; smaller ones use the classic kernels
     int Bc = 0;                     // rows the classic K/V buffers are sized for
     bool use_latent(int n) const { return latent && n > classic_rows; }
+    int smallm_rows = 0;            // bf16: batches of up to this many rows take the one-launch-per-projection path (kernels_smallm.h)
+    bool use_smallm(int n) const { return n <= smallm_rows && !use_latent(n); }
     std::map<std::string, std::vector<float>> host_w;
     std::map<std::string, std::vector<int64_t>> host_shape;
     std::vector<void*> allocs;
@@ -692,9 +696,87 @@ void latent_block(mocr_engine* e, bool self, int layer, int n, int t, const void
     gemm<T>(e, "gemm_dec_ctx", e->et, 16 * D, wv, bv, e->ctx_t, D, nullptr, n, 64, D, EPI_BIAS, 64, 1, 0, nullptr, 0, &hc);
 }
 
+template <int PRO, int EPI>
+void smallm_gemm(mocr_engine* e, const char* name, SmallMParams p) {
+    p.eps = e->cfg.ln_eps;
+    const int mt = (p.rows + 15) / 16;
+    if (mt < 1 || mt > 2 || p.N % SM_NT || (p.K != 768 && p.K != 3072) || (PRO == SM_PRO_LN && p.K != 768))
+        throw ArgError{"small-batch GEMM: unsupported shape", MOCR_ERR_UNSUPPORTED};
+    ProfScope ps(e, name, 2.0 * p.rows * p.N * p.K, (double)p.N * p.K * 2);
+    const dim3 grid(p.N / SM_NT), block(64 * SM_NW);
+    if constexpr (PRO == SM_PRO_LN) {
+        if (mt == 1) hipLaunchKernelGGL((smallm_gemm_kernel<PRO, EPI, 1, 3>), grid, block, SM_LDS(PRO, 1), e->stream, p);
+        else hipLaunchKernelGGL((smallm_gemm_kernel<PRO, EPI, 2, 3>), grid, block, SM_LDS(PRO, 2), e->stream, p);
+    } else {
+        if (p.K == 768) {
+            if (mt == 1) hipLaunchKernelGGL((smallm_gemm_kernel<PRO, EPI, 1, 3>), grid, block, SM_LDS(PRO, 1), e->stream, p);
+            else hipLaunchKernelGGL((smallm_gemm_kernel<PRO, EPI, 2, 3>), grid, block, SM_LDS(PRO, 2), e->stream, p);
+        } else {
+            if (mt == 1) hipLaunchKernelGGL((smallm_gemm_kernel<PRO, EPI, 1, 12>), grid, block, SM_LDS(PRO, 1), e->stream, p);
+            else hipLaunchKernelGGL((smallm_gemm_kernel<PRO, EPI, 2, 12>), grid, block, SM_LDS(PRO, 2), e->stream, p);
+        }
+    }
+    HIPCHECK(hipGetLastError());
+}
+
+// One greedy step of a SMALL bf16 batch (<= 32 rows, classic attention): 19 launches instead of 28 (kernels_smallm.h).
+// x_f32 / a_f32 / c_f32 hold PRE-LayerNorm sums here (s3 of the previous layer - or the embedding rows for layer 0 -,
+// s1, s2); ln_stats[k] the (mean, rstd) of s(k+1), published by the first projection that normalises it.
+void decode_step_smallm(mocr_engine* e, const DecState& st, int n, int t) {
+    using T = bf16_t;
+    const int D = e->D, F = e->F;
+    auto& w = e->w;
+    float* const st1 = e->ln_stats, * const st2 = e->ln_stats + 2 * e->Bp, * const st3 = e->ln_stats + 4 * e->Bp;
+    auto W = [](const void* q) { return reinterpret_cast<const bf16_t*>(q); };
+    for (int l = 0; l < e->cfg.dec_layers; ++l) {
+        const DecLayerW& L = w.dec[l];
+        const DecLayerW* P = l ? &w.dec[l - 1] : nullptr;        // the layer whose LayerNorm 3 produces this layer's input
+        SmallMParams q{};
+        q.rows = n; q.K = D; q.w = W(L.wqkv); q.N = 3 * D; q.out = e->slabs; q.ldo = 3 * D;
+        if (!P) { q.a_bf16 = W(e->x_t); smallm_gemm<SM_PRO_PLAIN, SM_EPI_RAW>(e, "sm_qkv", q); }
+        else { q.a_f32 = e->x_f32; q.ln_g = P->ln3g; q.ln_b = P->ln3b; q.stats_out = st3; smallm_gemm<SM_PRO_LN, SM_EPI_RAW>(e, "sm_qkv", q); }
+        dec_attn<T, true>(e, l, 1, n, L.bqkv, t + 1);
+        SmallMParams o{};
+        o.rows = n; o.K = D; o.a_bf16 = W(e->ctx_t); o.w = W(L.wo); o.N = D; o.bias = L.bo; o.out = e->a_f32; o.ldo = D;
+        o.resid = e->x_f32;
+        if (P) { o.resid_stats = st3; o.resid_g = P->ln3g; o.resid_b = P->ln3b; }
+        smallm_gemm<SM_PRO_PLAIN, SM_EPI_SUM>(e, "sm_proj", o);                       // s1 = ctx Wo^T + bo + layer input
+        SmallMParams c{};
+        c.rows = n; c.K = D; c.a_f32 = e->a_f32; c.ln_g = L.ln1g; c.ln_b = L.ln1b; c.stats_out = st1;
+        c.w = W(L.wqc); c.N = D; c.out = e->slabs; c.ldo = D;
+        smallm_gemm<SM_PRO_LN, SM_EPI_RAW>(e, "sm_qc", c);
+        dec_attn<T, false>(e, l, 1, n, L.bqc, e->S);
+        SmallMParams oc{};
+        oc.rows = n; oc.K = D; oc.a_bf16 = W(e->ctx_t); oc.w = W(L.woc); oc.N = D; oc.bias = L.boc; oc.out = e->c_f32; oc.ldo = D;
+        oc.resid = e->a_f32; oc.resid_stats = st1; oc.resid_g = L.ln1g; oc.resid_b = L.ln1b;
+        smallm_gemm<SM_PRO_PLAIN, SM_EPI_SUM>(e, "sm_proj", oc);                      // s2 = ctx Woc^T + boc + LN1(s1)
+        SmallMParams f1{};
+        f1.rows = n; f1.K = D; f1.a_f32 = e->c_f32; f1.ln_g = L.ln2g; f1.ln_b = L.ln2b; f1.stats_out = st2;
+        f1.w = W(L.w1); f1.N = F; f1.bias = L.b1; f1.out = e->h_t; f1.ldo = F;
+        smallm_gemm<SM_PRO_LN, SM_EPI_GELU_BF16>(e, "sm_fc1", f1);
+        SmallMParams f2{};
+        f2.rows = n; f2.K = F; f2.a_bf16 = W(e->h_t); f2.w = W(L.w2); f2.N = D; f2.bias = L.b2; f2.out = e->x_f32; f2.ldo = D;
+        f2.resid = e->c_f32; f2.resid_stats = st2; f2.resid_g = L.ln2g; f2.resid_b = L.ln2b;
+        smallm_gemm<SM_PRO_PLAIN, SM_EPI_SUM>(e, "sm_fc2", f2);                       // s3 = h W2^T + b2 + LN2(s2)
+    }
+    const DecLayerW& Z = w.dec[e->cfg.dec_layers - 1];
+    SmallMParams tr{};
+    tr.rows = n; tr.K = D; tr.a_f32 = e->x_f32; tr.ln_g = Z.ln3g; tr.ln_b = Z.ln3b;
+    tr.w = W(w.wt); tr.N = D; tr.bias = w.bt; tr.out = e->a_f32; tr.ldo = D;
+    smallm_gemm<SM_PRO_LN, SM_EPI_GELU_F32>(e, "sm_transform", tr);                   // gelu(LN3(s3) Wt^T + bt), pre-LayerNorm
+    SmallMParams v{};
+    v.rows = n; v.K = D; v.a_f32 = e->a_f32; v.ln_g = w.lntg; v.ln_b = w.lntb;
+    v.w = W(w.wv); v.N = e->V; v.out = e->slabs; v.ldo = e->V;
+    smallm_gemm<SM_PRO_LN, SM_EPI_RAW>(e, "sm_vocab", v);
+    dec_token<T, false>(e, st, 1, n);
+}
+
 // One greedy step for n rows; `t` is only used for the profiler's byte estimate.
 template <typename T>
 void decode_step(mocr_engine* e, const DecState& st, int n, int t) {
+    if constexpr (sizeof(T) == 2) {
+        if (e->use_smallm(n)) { decode_step_smallm(e, st, n, t); return; }
+    }
     const int D = e->D, F = e->F;
     auto& w = e->w;
     const void* xin = e->x_t;
@@ -805,6 +887,9 @@ template <typename T> void init_kernel_attrs() {
     set_max_lds(gemm256_kernel<EPI_BIAS_RESID>, l256);
     set_max_lds(gemm256_kernel<EPI_PATCH>, l256);
     set_max_lds(gemm256_kernel<EPI_BIAS_F32>, l256);
+    set_max_lds(smallm_gemm_kernel<SM_PRO_LN, SM_EPI_RAW, 2, 3>, SM_LDS(SM_PRO_LN, 2));
+    set_max_lds(smallm_gemm_kernel<SM_PRO_LN, SM_EPI_GELU_BF16, 2, 3>, SM_LDS(SM_PRO_LN, 2));
+    set_max_lds(smallm_gemm_kernel<SM_PRO_LN, SM_EPI_GELU_F32, 2, 3>, SM_LDS(SM_PRO_LN, 2));
     set_max_lds(latent_attn_kernel<true>, LAT_LDS);
     set_max_lds(latent_attn_kernel<false>, LAT_LDS);
     set_max_lds(latent_attn_fp8_kernel<true>, LAT8_LDS);
@@ -1248,6 +1333,7 @@ void allocate_lane(mocr_engine* e, int lane_id) {
     e->slabs = e->dalloc<float>((size_t)e->slab_cap);
     e->cand_val = e->dalloc<float>((size_t)Bp * (e->V / 64)); e->cand_idx = e->dalloc<int>((size_t)Bp * (e->V / 64));
     e->x_f32 = e->dalloc<float>(Bp * D); e->a_f32 = e->dalloc<float>(Bp * D); e->c_f32 = e->dalloc<float>(Bp * D);
+    e->ln_stats = e->dalloc<float>(3 * Bp * 2);
     e->x_t = e->dalloc<char>(Bp * D * esz); e->a_t = e->dalloc<char>(Bp * D * esz); e->c_t = e->dalloc<char>(Bp * D * esz);
     e->ctx_t = e->dalloc<char>(Bp * D * esz); e->z_t = e->dalloc<char>(Bp * D * esz);
     e->h_t = e->dalloc<char>(Bp * (size_t)e->F * esz);
@@ -1266,6 +1352,8 @@ void allocate_lanes(mocr_engine* e) {
     // non-temporal key loads: 320 rows 116 vs 126 ms, 384 rows 119 vs 129 ms, 448 / 512 rows (one graph shape) 159 vs 148 ms.
     e->classic_rows = !e->latent ? 0 : (e->cfg.flags & MOCR_FLAG_LATENT_ALWAYS) ? 0 : std::min(env_int("MOCR_CLASSIC_ROWS", 384), e->cfg.max_batch);
     e->Bc = e->latent ? e->classic_rows : e->Bp;
+    e->smallm_rows = (e->cfg.dtype == MOCR_BF16 && e->D == 768 && e->F == 3072 && e->V % SM_NT == 0 && !(e->cfg.flags & MOCR_FLAG_NO_SMALL_BATCH_PATH))
+                         ? std::min(SM_MAX_ROWS, env_int("MOCR_SMALLM_ROWS", SM_MAX_ROWS)) : 0;
     const int nl = std::max(1, std::min(16, (int)e->cfg.lanes));
     e->lanes.resize(nl);
     for (int i = 0; i < nl; ++i) {

@@ -13,6 +13,7 @@ MOCR_OK = 0
 MOCR_F32, MOCR_BF16 = 0, 1
 FLAG_SIMPLE_ATTENTION, FLAG_NO_GRAPH, FLAG_NO_EARLY_EXIT, FLAG_CLASSIC_ATTENTION = 1, 2, 4, 8
 FLAG_NO_FUSED_ARGMAX, FLAG_NO_FUSED_QQT, FLAG_LATENT_ALWAYS, FLAG_FP8_ATTENTION = 16, 32, 64, 128
+FLAG_NO_SMALL_BATCH_PATH = 256
 EPI_SLAB, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_PATCH, EPI_BIAS_F32 = range(6)
 
 
