@@ -251,7 +251,7 @@ def main():
     isolated = {}
     if extras and not light:
         more = {int(v) for v in os.environ.get("MOCR_BENCH_ISOLATED", "").split(",") if v}      # extra sizes (experiments)
-        for b in sorted({64, 256, B} | more):
+        for b in sorted({8, 64, 256, B} | more):
             if b > B:
                 continue
             for rep in range(3):                      # the first call captures the decode graphs of this batch size
