@@ -272,7 +272,16 @@ void launch_gemm_t(mocr_engine* e, const GemmParams& p0, int split, int ybatch) 
     constexpr int NST = gemm_ring<BM>();
     constexpr int lds = NST * (BM + BN) * 128;
     dim3 grid(ntm * p.ntn, ybatch, split);
-    hipLaunchKernelGGL((gemm_kernel<T, BM, BN, EPI, NST>), grid, dim3(256), lds, e->stream, p);
+    // Small grids (at most one block per CU: the encoder of a few crops) walk their K-tiles alone on a CU, and with the
+    // double buffer every K-tile costs a full memory round trip (1.25 us: QKV / O-proj / FC1 of one crop 15-16 us, FC2 with
+    // its 48 K-tiles 40 us).  A four-slot ring keeps three K-tiles in flight (r02)
+    static const int deep = env_int("MOCR_GEMM_DEEP", 1);
+    const int ktiles = p.k_per_split / (128 / (int)sizeof(T));
+    if (deep && ktiles >= 4 && (long long)grid.x * grid.y * grid.z <= e->num_cus) {
+        hipLaunchKernelGGL((gemm_kernel<T, BM, BN, EPI, 4>), grid, dim3(256), 4 * (BM + BN) * 128, e->stream, p);
+    } else {
+        hipLaunchKernelGGL((gemm_kernel<T, BM, BN, EPI, NST>), grid, dim3(256), lds, e->stream, p);
+    }
     HIPCHECK(hipGetLastError());
 }
 
@@ -448,15 +457,24 @@ void run_encoder(mocr_engine* e, const uint8_t* d_gray, int n) {
     // MOCR_ENC_TILE forces one tile code for the layer GEMMs (experiments); the patch embedding has its own epilogue
     // and stays on the 128x128 kernel unless a tile code that supports it (64/128/256) is forced
     static const int enc_tile_env = env_int("MOCR_ENC_TILE", 0);
-    const int ET = (enc_tile_env && enc_tile_env <= 256) ? enc_tile_env : 128;
+    const int ET = (enc_tile_env && enc_tile_env <= 256) ? enc_tile_env
+                   : ((long long)((MPATCH + 127) / 128) * (e->D / 128) * 5 <= 4LL * e->num_cus ? 64 : 128);
     // The 128x128 kernel walks QKV / FC1 in column groups of 9 / 12 N-tiles (a 1.7 / 2.3 MB weight slice stays in
     // the XCD's L2): +4 % / +2 % at M = 806,912 (r01).
     // Layer GEMMs: the 256x256 "wide" kernel (tile code 1024) once it fills the chip about three times over
     // (+12..15 % at M = 806,912, +10..20 % at M = 100,864; even at 12,608 rows), else the 128x128 kernel
+    // ... and 64 x 64 tiles while the 128 x 128 grid would leave CUs idle (up to ~0.8 blocks per CU): a block's K-tile costs
+    // ~1 us whatever the tile (8 DMA instructions per wave to issue against 32 MFMAs), so a few crops are done sooner as
+    // four times as many blocks of a quarter of the work.  r02, encoder of 1 / 4 / 8 crops: 1.41 / 1.49 / 1.54 -> 0.95 /
+    // 1.05 / 1.39 ms (QKV of one crop 16.0 -> 10.4 us, O-proj 16.7 -> 9.6, FC1 17.5 -> 11.2, FC2 40.1 -> 21.3)
+    auto small_tile = [&](int N) {
+        const long long blocks128 = (long long)((M + 127) / 128) * (N / 128);
+        return blocks128 * 5 <= 4LL * e->num_cus ? 64 : 128;
+    };
     auto layer_tile = [&](int N) {
         if (enc_tile_env) return enc_tile_env;
         const long long tiles = (long long)((M + 255) / 256) * (N / 256);
-        return (sizeof(T) == 2 && tiles >= 3LL * e->num_cus) ? 2048 : 128;
+        return (sizeof(T) == 2 && tiles >= 3LL * e->num_cus) ? 2048 : small_tile(N);
     };
     // per-GEMM overrides for experiments: MOCR_ENC_TILE_QKV / _O / _FC1 / _FC2 (tile codes as in gemm())
     static const int tq_env = env_int("MOCR_ENC_TILE_QKV", 0), to_env = env_int("MOCR_ENC_TILE_O", 0),
@@ -838,7 +856,8 @@ template <typename T>
 void run_cross_kv(mocr_engine* e, int n) {
     const int M = n * e->S;
     static const int enc_tile_env = env_int("MOCR_ENC_TILE", 0);
-    const int ET = enc_tile_env ? enc_tile_env : ((sizeof(T) == 2 && M >= 256 * 48) ? 256 : 128);
+    const bool few_blocks = (long long)((M + 127) / 128) * (e->NCKV / 128) * 5 <= 4LL * e->num_cus;      // see run_encoder
+    const int ET = enc_tile_env ? enc_tile_env : ((sizeof(T) == 2 && M >= 256 * 48) ? 256 : few_blocks ? 64 : 128);
     gemm<T>(e, "gemm_cross_kv", e->ENC, e->D, e->w.wckv, e->w.bckv, e->CKV, e->NCKV, nullptr, M, e->NCKV, e->D,
             EPI_BIAS, ET, 1);
 }
@@ -869,6 +888,20 @@ template <typename T> void init_kernel_attrs() {
     set_max_lds(gemm_kernel<T, 64, 64, EPI_PATCH, 2>, l64);
     set_max_lds(gemm_kernel<T, 64, 64, EPI_BIAS_F32, 2>, l64);
     set_max_lds(gemm_kernel<T, 64, 64, EPI_ARGMAX, 2>, l64);
+    set_max_lds(gemm_kernel<T, 128, 128, EPI_SLAB, 4>, 2 * l128);
+    set_max_lds(gemm_kernel<T, 128, 128, EPI_BIAS, 4>, 2 * l128);
+    set_max_lds(gemm_kernel<T, 128, 128, EPI_BIAS_GELU, 4>, 2 * l128);
+    set_max_lds(gemm_kernel<T, 128, 128, EPI_BIAS_RESID, 4>, 2 * l128);
+    set_max_lds(gemm_kernel<T, 128, 128, EPI_PATCH, 4>, 2 * l128);
+    set_max_lds(gemm_kernel<T, 128, 128, EPI_BIAS_F32, 4>, 2 * l128);
+    set_max_lds(gemm_kernel<T, 128, 128, EPI_ARGMAX, 4>, 2 * l128);
+    set_max_lds(gemm_kernel<T, 64, 64, EPI_SLAB, 4>, 2 * l64);
+    set_max_lds(gemm_kernel<T, 64, 64, EPI_BIAS, 4>, 2 * l64);
+    set_max_lds(gemm_kernel<T, 64, 64, EPI_BIAS_GELU, 4>, 2 * l64);
+    set_max_lds(gemm_kernel<T, 64, 64, EPI_BIAS_RESID, 4>, 2 * l64);
+    set_max_lds(gemm_kernel<T, 64, 64, EPI_PATCH, 4>, 2 * l64);
+    set_max_lds(gemm_kernel<T, 64, 64, EPI_BIAS_F32, 4>, 2 * l64);
+    set_max_lds(gemm_kernel<T, 64, 64, EPI_ARGMAX, 4>, 2 * l64);
     set_max_lds(enc_attn_simple_kernel<T>, (200 * 65 + 200 * 64 + 4 * 64 + 4 * 256) * 4);
     set_max_lds(enc_attn_mfma_kernel, ENC_SP * 128 + 64 * ENC_VT_LD * 2);
     set_max_lds(dec_qqt_kernel, 160 * 1024);
