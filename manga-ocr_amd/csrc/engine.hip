@@ -272,10 +272,11 @@ void launch_gemm_t(mocr_engine* e, const GemmParams& p0, int split, int ybatch) 
     constexpr int NST = gemm_ring<BM>();
     constexpr int lds = NST * (BM + BN) * 128;
     dim3 grid(ntm * p.ntn, ybatch, split);
-    // Small grids (at most one block per CU: the encoder of a few crops) walk their K-tiles alone on a CU, and with the
-    // double buffer every K-tile costs a full memory round trip (1.25 us: QKV / O-proj / FC1 of one crop 15-16 us, FC2 with
-    // its 48 K-tiles 40 us).  A four-slot ring keeps three K-tiles in flight (r02)
-    static const int deep = env_int("MOCR_GEMM_DEEP", 1);
+    // Small grids (at most one block per CU: the encoder of a few crops) walk their K-tiles alone on a CU at ~1 us per
+    // K-tile.  A four-slot ring (three K-tiles in flight instead of one) was built to hide a memory round trip there and
+    // changed nothing (r02: QKV of one crop 16.1 vs 15.9 us, FC2 40.4 vs 40.1): the cost is the DMA issue, not the
+    // latency - what helped is smaller tiles (run_encoder).  Kept for experiments: MOCR_GEMM_DEEP=1
+    static const int deep = env_int("MOCR_GEMM_DEEP", 0);
     const int ktiles = p.k_per_split / (128 / (int)sizeof(T));
     if (deep && ktiles >= 4 && (long long)grid.x * grid.y * grid.z <= e->num_cus) {
         hipLaunchKernelGGL((gemm_kernel<T, BM, BN, EPI, 4>), grid, dim3(256), 4 * (BM + BN) * 128, e->stream, p);
