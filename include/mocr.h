@@ -158,8 +158,8 @@ int mocr_preprocess(mocr_engine* e, const mocr_image* images, int32_t n, uint8_t
  * lanes; mocr_synchronize() schedules every submitted batch to completion (greedy steps in
  * chunks, stopping a batch once all of its rows have emitted EOS) and waits for the GPU. */
 int mocr_recognize_device(mocr_engine* e, const void* d_gray, int32_t n, void* d_out_ids, void* d_out_len);
-/* generate(max_length=...) of the batches submitted with mocr_recognize_device from now on (2 <= max_len <= the
- * engine's max_len; rows are still max_len wide).  The reference always calls generate with 300; a speech bubble is
+/* generate(max_length=...) of every batch submitted from now on, whatever the entry point (2 <= max_len <= the
+ * engine's max_len; rows are still max_len wide; mocr_recognize_gray_host's own argument overrides it).  The reference always calls generate with 300; a speech bubble is
  * typically ~32 tokens (SURVEY.md §8d reports both regimes). */
 int mocr_set_generate_max_length(mocr_engine* e, int32_t max_len);
 int mocr_synchronize(mocr_engine* e);

@@ -1585,7 +1585,7 @@ int mocr_recognize(mocr_engine* e, const uint8_t* images, int32_t n, int32_t h, 
         std::lock_guard<std::mutex> lk(e->mu);
         require_ready(e, n, false);
         HIPCHECK(hipSetDevice(e->cfg.device));
-        recognize_host_chunks(e, images, n, h, w, row_stride, image_stride, channels, e->cfg.max_len, out_ids, out_len);
+        recognize_host_chunks(e, images, n, h, w, row_stride, image_stride, channels, e->gen_max_len, out_ids, out_len);
     });
 }
 
@@ -1731,7 +1731,7 @@ static void recognize_planes(mocr_engine* e, const uint8_t* d_gray, int n, int32
         Job j;
         j.src = d_gray + (size_t)base * plane; j.src_host = false; j.channels = 1;
         j.row_stride = e->cfg.image_size; j.image_stride = (int64_t)plane;
-        j.n = std::min(e->cfg.max_batch, n - base); j.max_len = e->cfg.max_len;
+        j.n = std::min(e->cfg.max_batch, n - base); j.max_len = e->gen_max_len;
         j.out_ids = out_ids + (size_t)base * e->cfg.max_len; j.out_len = out_len + base; j.out_host = true;
         e->pending.push_back(j);
     }
