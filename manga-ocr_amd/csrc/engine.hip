@@ -485,17 +485,52 @@ void run_encoder(mocr_engine* e, const uint8_t* d_gray, int n) {
     gemm<T>(e, "gemm_patch_embed", e->Hb, P * P, w.wpe, w.bpe, e->X, D, nullptr, MPATCH, D, P * P, EPI_PATCH, ET, 1, 0,
             w.pos_enc, NP);
     const int impl = (e->cfg.flags & MOCR_FLAG_SIMPLE_ATTENTION) ? 0 : 1;
+    // A few crops (the 64 x 64 grid of the two N = 768 GEMMs is at most one block per CU: up to 5 crops): O-proj and FC2
+    // are split over K into fp32 slabs - for one crop 12 / 48 K-tiles walked alone by 48 blocks become 4 / 6 K-tiles on
+    // 144 / 384 blocks - and the LayerNorm launch that follows anyway finishes them (bias + slabs + residual, in place,
+    // fixed order; layernorm_slab_kernel).  r02, encoder of 1 / 2 / 4 crops: 1.07 / 1.07 / 1.12 -> 0.88 / 0.90 / 1.01 ms
+    // (one crop: FC2 28.3 -> 9.3 us, O-proj 11.8 -> 7.7, the LayerNorm behind them 6.6 -> 10.3)
+    static const int enc_split_env = env_int("MOCR_ENC_SPLITK", 1);
+    const long long blocks64 = (long long)((M + 63) / 64) * (D / 64);
+    int split_o = 1, split_2 = 1;
+    static const int enc_split_blocks = env_int("MOCR_ENC_SPLITK_BLOCKS", 0);      // largest unsplit 64 x 64 grid that is split (0: one block per CU)
+    if (enc_split_env && !enc_tile_env && ETO == 64 && blocks64 <= (enc_split_blocks ? enc_split_blocks : e->num_cus)) {
+        split_o = 3; split_2 = 8;
+        while (split_2 > 1 && (long long)M * D * split_2 > e->slab_cap) split_2 >>= 1;
+        if ((long long)M * D * split_o > e->slab_cap) split_o = 1;
+        if (split_2 < 2) split_2 = 1;
+    }
+    const float* pend_bias = nullptr;      // bias of a split GEMM whose slabs the next LayerNorm has to add to X
+    int pend_slabs = 0;
+    auto norm = [&](const float* g, const float* b, void* out) {
+        if (!pend_slabs) { layernorm<T>(e, e->X, g, b, out, M); return; }
+        ProfScope ps(e, "layernorm_slab", 0, (double)M * D * (4.0 * (pend_slabs + 2) + sizeof(T)));
+        hipLaunchKernelGGL((layernorm_slab_kernel<T, 768>), dim3((M + 3) / 4), dim3(256), 0, e->stream, e->X, e->slabs, pend_slabs,
+                           (long long)M * D, pend_bias, g, b, reinterpret_cast<T*>(out), M, e->cfg.ln_eps);
+        HIPCHECK(hipGetLastError());
+        pend_slabs = 0;
+    };
     for (int l = 0; l < e->cfg.enc_layers; ++l) {
         const EncLayerW& L = w.enc[l];
-        layernorm<T>(e, e->X, L.ln1g, L.ln1b, e->Xn, M);
+        norm(L.ln1g, L.ln1b, e->Xn);
         gemm<T>(e, "gemm_enc_qkv", e->Xn, D, L.wqkv, L.bqkv, e->QKV, 3 * D, nullptr, M, 3 * D, D, EPI_BIAS, ETQ, 1, 0, nullptr, 0, nullptr, 9);
         enc_attention<T>(e, e->QKV, e->CTX, n, impl);
-        gemm<T>(e, "gemm_enc_oproj", e->CTX, D, L.wo, L.bo, e->X, D, e->X, M, D, D, EPI_BIAS_RESID, ETO, 1);
-        layernorm<T>(e, e->X, L.ln2g, L.ln2b, e->Xn, M);
+        if (split_o > 1) {
+            gemm<T>(e, "gemm_enc_oproj", e->CTX, D, L.wo, nullptr, e->slabs, D, nullptr, M, D, D, EPI_SLAB, 64, split_o, (long long)M * D);
+            pend_bias = L.bo; pend_slabs = split_o;
+        } else {
+            gemm<T>(e, "gemm_enc_oproj", e->CTX, D, L.wo, L.bo, e->X, D, e->X, M, D, D, EPI_BIAS_RESID, ETO, 1);
+        }
+        norm(L.ln2g, L.ln2b, e->Xn);
         gemm<T>(e, "gemm_enc_fc1", e->Xn, D, L.w1, L.b1, e->Hb, F, nullptr, M, F, D, EPI_BIAS_GELU, ET1, 1, 0, nullptr, 0, nullptr, 12);
-        gemm<T>(e, "gemm_enc_fc2", e->Hb, F, L.w2, L.b2, e->X, D, e->X, M, D, F, EPI_BIAS_RESID, ET2, 1);
+        if (split_2 > 1) {
+            gemm<T>(e, "gemm_enc_fc2", e->Hb, F, L.w2, nullptr, e->slabs, D, nullptr, M, D, F, EPI_SLAB, 64, split_2, (long long)M * D);
+            pend_bias = L.b2; pend_slabs = split_2;
+        } else {
+            gemm<T>(e, "gemm_enc_fc2", e->Hb, F, L.w2, L.b2, e->X, D, e->X, M, D, F, EPI_BIAS_RESID, ET2, 1);
+        }
     }
-    layernorm<T>(e, e->X, w.lnfg, w.lnfb, e->ENC, M);
+    norm(w.lnfg, w.lnfb, e->ENC);
 }
 
 // ---------------------------------------------------------------------------------------- decoder

@@ -48,6 +48,54 @@ __global__ void cls_rows_kernel(const float* __restrict__ cls, const float* __re
     X[(size_t)b * tokens * D + d] = cls[d] + pos[d];
 }
 
+// The encoder of a few crops splits its O-proj / FC2 GEMMs over K (engine.hip, run_encoder): the LayerNorm that follows
+// first finishes them - x += bias + sum of the fp32 slabs (fixed order: deterministic), written back in place as the
+// residual stream - and then normalises as layernorm_kernel does.
+template <typename TO, int D>
+__global__ __launch_bounds__(256) void layernorm_slab_kernel(float* __restrict__ x, const float* __restrict__ slabs, int nslab,
+                                                             long long slab_stride, const float* __restrict__ bias,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             TO* __restrict__ out, int M, float eps) {
+    static_assert(D % 256 == 0, "row = k * 64 lanes * 4");
+    constexpr int V = D / 256;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= M) return;
+    float* xr = x + (size_t)row * D;
+    const float* sr = slabs + (size_t)row * D;
+    float v[V * 4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const int c = i * 256 + lane * 4;
+        float4 t = *reinterpret_cast<const float4*>(xr + c);
+        const float4 bb = *reinterpret_cast<const float4*>(bias + c);
+        float4 acc = *reinterpret_cast<const float4*>(sr + c);
+        for (int k = 1; k < nslab; ++k) {
+            const float4 u = *reinterpret_cast<const float4*>(sr + (size_t)k * slab_stride + c);
+            acc.x += u.x; acc.y += u.y; acc.z += u.z; acc.w += u.w;
+        }
+        t.x += acc.x + bb.x; t.y += acc.y + bb.y; t.z += acc.z + bb.z; t.w += acc.w + bb.w;
+        *reinterpret_cast<float4*>(xr + c) = t;
+        v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
+        s += (t.x + t.y) + (t.z + t.w);
+    }
+    const float mean = wave_sum(s) * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < V * 4; ++i) { const float d = v[i] - mean; q += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / D) + eps);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const int c = i * 256 + lane * 4;
+        const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+        const float4 b = *reinterpret_cast<const float4*>(beta + c);
+        float o[4] = {(v[4 * i] - mean) * rstd * g.x + b.x, (v[4 * i + 1] - mean) * rstd * g.y + b.y,
+                      (v[4 * i + 2] - mean) * rstd * g.z + b.z, (v[4 * i + 3] - mean) * rstd * g.w + b.w};
+        elem<TO>::st4(out + (size_t)row * D + c, o);
+    }
+}
+
 // LayerNorm over rows of 768 fp32 (eps 1e-12: two-pass statistics in fp32, TF/models/vit/
 // configuration_vit.py:58).  One wave per row, 12 elements per lane as 3 float4.
 template <typename TO, int D>

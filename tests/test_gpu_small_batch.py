@@ -44,14 +44,19 @@ def test_small_batch_path_logits_agree_with_the_generic_path_and_the_oracle(rows
 
 
 def test_small_batch_rows_do_not_depend_on_the_batch():
-    """A crop decodes to the same ids alone, in a 16-row and in a 32-row batch (one or two row tiles, padding rows)."""
+    """A crop decodes to the same ids whatever else is in its batch, as long as the batch stays in one kernel regime: up to 5
+    crops the encoder splits its O-proj / FC2 GEMMs over K (another summation order), from 6 to 32 rows it does not."""
     eng = engine("bf16", max_batch=32, flags=CLASSIC)
     gray = crops(4343, 32)
     full, _ = eng.recognize_gray(gray, max_len=40)
-    for n in (1, 3, 16, 19):
+    for n in (6, 16, 19):
         ids, lens = eng.recognize_gray(gray[:n], max_len=40)
         np.testing.assert_array_equal(ids, full[:n])
         assert (lens == 40).all()
+    five, _ = eng.recognize_gray(gray[:5], max_len=40)
+    for n in (1, 2, 4):
+        ids, _ = eng.recognize_gray(gray[:n], max_len=40)
+        np.testing.assert_array_equal(ids, five[:n])
 
 
 def test_small_batch_early_eos_lengths_and_padding_match_the_generic_path():
