@@ -427,7 +427,10 @@ void enc_attention(mocr_engine* e, const void* qkv, void* ctx, int n, int impl) 
     if (impl == 1 && sizeof(T) == 2) {
         ProfScope ps(e, "enc_attn_mfma", flops, bytes);
         constexpr int lds = ENC_SP * 128 + 64 * ENC_VT_LD * 2;
-        hipLaunchKernelGGL(enc_attn_mfma_kernel, dim3(n * H), dim3(256), lds, e->stream,
+        // a few crops: two blocks per (image, head), four query tiles each, while n * H blocks would cover less than half the chip
+        static const int qsplit_env = env_int("MOCR_ENC_ATTN_QSPLIT", 1);
+        const int ysplit = (qsplit_env && n * H * 2 <= e->num_cus) ? 2 : 1;
+        hipLaunchKernelGGL(enc_attn_mfma_kernel, dim3(n * H, ysplit), dim3(256), lds, e->stream,
                            reinterpret_cast<const bf16_t*>(qkv), reinterpret_cast<bf16_t*>(ctx), H, 3 * e->D, e->D);
     } else {
         ProfScope ps(e, "enc_attn_simple", flops, bytes);

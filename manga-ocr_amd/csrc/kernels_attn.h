@@ -156,12 +156,13 @@ __global__ __launch_bounds__(256, 2) void enc_attn_mfma_kernel(const bf16_t* __r
     }
     __syncthreads();
 
-    for (int qt = wave; qt < ENC_SP / 32; qt += 4) {
+    // gridDim.y = 2 (a few crops: n * H blocks would leave most CUs idle): block y takes the query tiles 4 y .. 4 y + 3
+    for (int qt = wave + (gridDim.y > 1 ? 4 * (int)blockIdx.y : 0); qt < ENC_SP / 32; qt += 4 * (int)gridDim.y) {
         const int q = qt * 32 + r32;                // (padded queries are computed from a clamped row, not stored)
         // B operand of S^T = K.Q^T : lane holds Q[q][16s + 8hh .. +7]
         bf16x8 qf[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) qf[s] = qt == wave ? qpre[0][s] : qpre[1][s];
+        for (int s = 0; s < 4; ++s) qf[s] = qt < 4 ? qpre[0][s] : qpre[1][s];
         f32x16 st[7];
 #pragma unroll
         for (int kt = 0; kt < 7; ++kt) {
