@@ -26,13 +26,22 @@ struct QqtParams {
     bf16_t* qt;           // [rows_pad][16][768]
 };
 
-#define QQT_LDS (2 * (128 + 64) * 128 + 128 * 128)      // phase-1 ring (2 x 24 KiB; phase 2: 2 x 16 KiB of it) + the q tile
+// Ring depth of phase 1 (r02).  The first form double-buffered both phases behind full vmcnt(0) drains: every one of the
+// 12 K-tiles and 6 Wk^T slices then costs a whole memory round trip (one tile in flight: 24 us per launch at 2560 rows
+// whatever the rows, i.e. pure latency).  Now phase 1 keeps three K-tiles in flight (counted vmcnt, loads only), and
+// phase 2 requests ALL six slices at once into the ring phase 1 has left (6 x 16 KiB = the 4 x 24 KiB ring), waits once
+// and never again - its stores are fire-and-forget: 25.0 -> 20.6 us at 2560 rows (what is left is the 47 MB of Qt the
+// launch writes).  -DQQT_NST=2 builds the first form for A/B runs.
+#ifndef QQT_NST
+#define QQT_NST 4
+#endif
+#define QQT_LDS (QQT_NST * (128 + 64) * 128 + 128 * 128)      // phase-1 ring (phase 2: the Wk^T slices in it) + the q tile
 
 __global__ __launch_bounds__(256, 2) void dec_qqt_kernel(QqtParams p) {
     constexpr int D = 768, KT = D / 64;                 // 12 K-tiles of 64 in phase 1
     constexpr int A_BYTES = 128 * 128, STAGE = (128 + 64) * 128;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const sQ = smem + 2 * STAGE;                  // [128 rows][64 dims] bf16, swizzled 128-B rows
+    char* const sQ = smem + QQT_NST * STAGE;            // [128 rows][64 dims] bf16, swizzled 128-B rows
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int l15 = lane & 15, g4 = lane >> 4;
@@ -64,15 +73,23 @@ __global__ __launch_bounds__(256, 2) void dec_qqt_kernel(QqtParams p) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) qa[j][i][r] = 0.f;
-    stage1(0, 0);
+#pragma unroll
+    for (int i = 0; i < QQT_NST - 1; ++i) stage1(i, i);
     for (int t = 0; t < KT; ++t) {
-        // lgkmcnt(0) too: hipcc sinks the last MFMAs of the previous K-tile (and the wait for their fragments) below
-        // this barrier, and behind it the buffer those fragment reads come from is handed to the DMA
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        // K-tile t has landed: this wave issued 6 DMA instructions per tile, and only loads are in its queue here, so the
+        // count of the younger tiles' instructions may stay in flight.  lgkmcnt(0) too: hipcc sinks the last MFMAs of
+        // the previous K-tile (and the wait for their fragments) below this barrier, and behind it the buffer those
+        // fragment reads come from is handed to the DMA
+        {
+            const int newer = KT - 1 - t < QQT_NST - 2 ? KT - 1 - t : QQT_NST - 2;
+            if (newer >= 2) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+            else if (newer == 1) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (t + 1 < KT) stage1(t + 1, (t + 1) & 1);
-        const char* sa = smem + (t & 1) * STAGE;
+        if (t + QQT_NST - 1 < KT) stage1(t + QQT_NST - 1, (t + QQT_NST - 1) % QQT_NST);
+        const char* sa = smem + (t % QQT_NST) * STAGE;
         const char* sb = sa + A_BYTES;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -124,7 +141,12 @@ __global__ __launch_bounds__(256, 2) void dec_qqt_kernel(QqtParams p) {
         }
     }
     __syncthreads();                                    // every wave is past its last phase-1 fragment reads: the ring is free
+#if QQT_NST >= 4
+#pragma unroll
+    for (int k = 0; k < 6; ++k) stage2(k, k);           // all six slices at once: 96 KiB = the whole ring
+#else
     stage2(0, 0);
+#endif
 
     // ---------------- phase 2: Qt tile = q tile . (Wk_h^T/8) slices.  Wave (wm, wn): rows 64 wm .. +63, columns 64 wn .. +63 of a slice
     bf16x8 fq[2][4];     // q fragments of this wave's 64 rows, both 32-deep k-steps: the same for all six slices
@@ -136,12 +158,21 @@ __global__ __launch_bounds__(256, 2) void dec_qqt_kernel(QqtParams p) {
             fq[s][i] = *(const bf16x8*)(sQ + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
         }
     bf16_t* const orow0 = p.qt + ((size_t)(m0 + wm * 64 + l15) * 16 + h) * D + wn * 64;
+#if QQT_NST >= 4
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // the six slices landed (nothing else is in flight)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#endif
     for (int nt2 = 0; nt2 < 6; ++nt2) {
+#if QQT_NST >= 4
+        const char* sw = smem + nt2 * A_BYTES;
+#else
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // slice nt2 landed (and the previous slice's stores acknowledged)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (nt2 + 1 < 6) stage2(nt2 + 1, (nt2 + 1) & 1);      // its buffer was last read one slice ago
         const char* sw = smem + (nt2 & 1) * A_BYTES;
+#endif
         f32x4 acc[4][4];     // [column tile j][row tile i]
 #pragma unroll
         for (int j = 0; j < 4; ++j)
