@@ -551,9 +551,12 @@ static int pick_split(int N, int K, int kt, int rows, long long slab_cap_per_row
     // Every extra slab is an fp32 [rows,N] write plus a read by the consumer, so fat batches
     // (many row tiles) split less.
     // measured (r01): 150 for 64..1024 rows; fat batches (>= 2048 rows) gain from one more halving of K
-    // (FC2 at 4096 rows: 48 -> 33 us)
+    // (FC2 at 4096 rows: 48 -> 33 us: 192 tiles -> 384 blocks).  r02: 200 instead of 300 there - the same split at 4096
+    // rows, but the N = 768 projections of a 2560-row batch (120 tiles) stop at 2 slabs instead of 4: the add + LayerNorm
+    // behind them is bound by its slab traffic (bench 6.30-6.36 k -> 6.44-6.45 k crops/s; targets 60 / 100 / 450 / 600: 6.30 /
+    // 6.32 / 6.35 / 6.10 k)
     static const int target_env = env_int("MOCR_DEC_BLOCKS", 0);
-    const int target = target_env ? target_env : (rows >= 2048 ? 300 : 150);
+    const int target = target_env ? target_env : (rows >= 2048 ? 200 : 150);
     const int tile = dec_tile(rows);
     const int tiles = (N / tile) * ((rows + tile - 1) / tile);
     const int ktiles = K / kt;
