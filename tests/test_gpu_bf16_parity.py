@@ -21,7 +21,8 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 BF16_LOGIT_TOL = 3e-2     # max |logit - oracle logit| accepted, teacher-forced (measured: 1.2e-2 .. 1.4e-2)
-BF16_GAP_TOL = 2.5e-2     # a first divergence is accepted only where the reference's own top-2 margin is below this (measured: <= 1.02e-2)
+BF16_GAP_TOL = 1.5e-2     # a first divergence is accepted only where the reference's own top-2 margin is below this (measured: <= 1.09e-2;
+                          # r02 ran with 2.5e-2)
 
 
 @pytest.fixture(scope="module")
@@ -75,6 +76,73 @@ def test_bf16_fat_batch_free_running_ids(gold, rows, path):
     gaps = np.concatenate([gold["gaps_seed0"], gold["gaps_seed0"][:rows - 256]]).astype(np.float32)
     first_divergences(ids, want, gaps, f"bf16 auto path, {rows} rows ({path} attention), plain weights")
     np.testing.assert_array_equal(ids[:rows - 256], ids[256:])          # a row does not depend on its position in the batch
+
+
+@pytest.mark.parametrize("rows,lanes,max_batch", [(1024, 1, 1024), (2560, 2, 5120)])
+def test_bf16_bench_shape_free_running_ids(gold, rows, lanes, max_batch):
+    """The shapes bench.py's timed region runs: device-resident steps of 256 crops submitted back to back
+    (mocr_recognize_device) and merged by the engine - 4 x 256 -> ONE 1024-row batch (128 x 128 decode tiles, the fused
+    query kernel, wide encoder GEMMs), and 20 x 256 on a two-lane engine -> the queue split into 2 x 2560 rows (the
+    bench's default: split-K target of >= 2048 rows, both lanes in flight; max_batch = the queue's 5120 rows, so nothing is
+    pumped before the whole queue is in and the idle-lane split of pump_once decides the batch shapes, as in bench.py).  Every step is the 256 golden crops, so every
+    row is held to the reference by the first-divergence rule and a crop must decode to the same ids whatever step,
+    position or lane it was in."""
+    from gpu_util import drop_engines
+    drop_engines()                                  # fat workspaces: give the HBM of the cached engines back first
+    eng = engine("bf16", max_batch=max_batch, auto_path=True, lanes=lanes)
+    base = crops(777, 256)
+    steps = rows // 256 * lanes
+    dg = torch.from_numpy(base).cuda()
+    d_ids = torch.zeros((steps, 256, 300), dtype=torch.int32, device="cuda")
+    d_len = torch.zeros((steps, 256), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    for i in range(steps):
+        eng.recognize_device(dg, 256, d_ids[i], d_len[i])
+    eng.synchronize()
+    torch.cuda.synchronize()
+    ids = d_ids.cpu().numpy()
+    assert (d_len.cpu().numpy() == 300).all() and (ids[:, :, 0] == 2).all()
+    gaps = gold["gaps_seed0"].astype(np.float32)
+    first_divergences(ids[0], gold["ids_seed0"], gaps, f"bf16 bench shape, {steps} x 256 crops merged into {lanes} x {rows} rows, step 0")
+    first_divergences(ids[-1], gold["ids_seed0"], gaps, f"bf16 bench shape, {steps} x 256 crops merged into {lanes} x {rows} rows, last step")
+    for i in range(1, steps):
+        np.testing.assert_array_equal(ids[i], ids[0], err_msg=f"step {i} of the merged queue decodes differently from step 0")
+    drop_engines()
+
+
+def test_bf16_2560_row_batch_teacher_forced_logits(gold):
+    """One 2560-row internal batch (the row count of the bench's lanes), teacher-forced with the reference's ids for 24
+    steps: rows 0..7 and 2552..2559 against the CPU oracle - the kernels that only switch on at fat batches (fused query
+    kernel, 128 x 128 decode tiles, two-slab split-K, wide encoder GEMMs at M = 504,320) against the reference itself."""
+    from gpu_util import drop_engines
+    drop_engines()
+    rows, T = 2560, 24
+    eng = engine("bf16", max_batch=rows, auto_path=True)
+    base = crops(777, 256)
+    gray = np.concatenate([base] * (rows // 256))
+    forced = np.concatenate([gold["ids_seed0"][:, :T]] * (rows // 256)).astype(np.int32)
+    dg = torch.from_numpy(gray).cuda()
+    torch.cuda.synchronize()
+    got_all = eng.decode_logits(dg, rows, forced)
+    sel = list(range(8)) + list(range(rows - 8, rows))
+    got = got_all[sel]
+    del got_all
+    o = oracle()
+    src = [r % 256 for r in sel]
+    enc = o.encode(o.preprocess_gray(base[src]))
+    _, ref = o.generate(enc, return_logits=True, forced_ids=gold["ids_seed0"][src, :T + 1].astype(np.int64))
+    ref = ref[:, :T]
+    d = np.abs(got - ref)
+    srt = np.sort(ref, axis=-1)
+    gap = srt[..., -1] - srt[..., -2]
+    agree = got.argmax(-1) == ref.argmax(-1)
+    report(f"teacher-forced logits bf16, ONE {rows}-row batch (rows 0..7 and {rows - 8}..{rows - 1} checked, {T} steps) vs oracle: max abs err "
+           f"{d.max():.3e}, mean {d.mean():.3e}, argmax agreement {agree.mean():.4f}; disagreements all at reference margins < "
+           f"{gap[~agree].max() if (~agree).any() else 0:.3e}")
+    assert np.isfinite(got).all() and d.max() <= BF16_LOGIT_TOL
+    assert (gap[~agree] < BF16_LOGIT_TOL).all(), "argmax differs where the reference's margin exceeds the logit tolerance"
+    assert agree.mean() >= 0.97
+    drop_engines()
 
 
 @pytest.mark.parametrize("name,flags,auto", [("classic", 8, False), ("latent", 0, False), ("auto", 0, True)])

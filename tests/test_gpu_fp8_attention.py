@@ -111,30 +111,70 @@ def test_latent_attention_fp8_kernel(L, n):
     assert err_q <= 0.04 * scale + 2e-2 and err_e <= 0.0625 * np.abs(xe).max() + 0.04 * scale + 2e-2
 
 
-def test_fp8_attention_engine_accuracy_report(golden_dir):
-    """The whole engine with fp8 attention against the fp32 oracle, next to the bf16 engine: teacher-forced logits over 47
-    steps and free-running ids (256-row golden, first 64 rows) - REPORTED; asserted only loosely (finite, sane)."""
+FP8_LOGIT_TOL = 6e-2      # teacher-forced |logit - oracle| (measured 3.2e-2; the bf16 engine: 1.3e-2 under a 3e-2 bound)
+FP8_GAP_TOL = 2.5e-2      # a free-running row may leave the reference only where the reference's own top-2 margin is below this
+
+
+def test_fp8_attention_engine_against_the_reference(golden_dir):
+    """The whole engine with fp8 attention against the fp32 oracle and the transformers goldens, next to the bf16 engine:
+    teacher-forced logits over 47 steps (max error, argmax agreement, disagreements only at small reference margins) and
+    free-running ids of the first 64 golden rows held to the SAME first-divergence rule as the bf16 engine."""
     g = np.load(os.path.join(golden_dir, "bf16_parity.npz"))
     gray = crops(777, 256)[:64]
     forced = g["ids_seed0"][:64, :47].astype(np.int32)
     o = oracle()
     enc = o.encode(o.preprocess_gray(gray[:8]))
-    _, ref = o.generate(enc, return_logits=True, forced_ids=g["ids_seed0"][:8, :47].astype(np.int64))
+    _, ref = o.generate(enc, return_logits=True, forced_ids=g["ids_seed0"][:8, :48].astype(np.int64))
+    ref = ref[:, :47]
+    srt = np.sort(ref, axis=-1)
+    margin = srt[..., -1] - srt[..., -2]
     dg = torch.from_numpy(gray).cuda()
     torch.cuda.synchronize()
-    res = {}
-    for name, flags in (("bf16 latent", LATENT_ALWAYS), ("fp8 attention", LATENT_ALWAYS | FP8)):
+    for name, flags, ltol, gtol in (("bf16 latent", LATENT_ALWAYS, 3e-2, FP8_GAP_TOL), ("fp8 attention", LATENT_ALWAYS | FP8, FP8_LOGIT_TOL, FP8_GAP_TOL)):
         eng = engine("bf16", max_batch=64, flags=flags)
         lg = eng.decode_logits(dg, 64, forced)[:8]
         d = np.abs(lg - ref)
-        agree = (lg.argmax(-1) == ref.argmax(-1)).mean()
+        agree = lg.argmax(-1) == ref.argmax(-1)
         ids, lens = eng.recognize(gray)
         want = g["ids_seed0"][:64].astype(np.int32)
         first = [int(np.nonzero(ids[b] != want[b])[0][0]) if (ids[b] != want[b]).any() else 300 for b in range(64)]
         gaps = [float(g["gaps_seed0"][b, t - 1]) for b, t in enumerate(first) if t < 300]
-        res[name] = (d.max(), d.mean(), agree, np.mean(first), max(gaps) if gaps else 0.0)
-        report(f"[{name}] teacher-forced logits vs oracle: max abs err {d.max():.3e}, mean {d.mean():.3e}, argmax agreement {agree:.4f}; "
-               f"free-running 64 rows x 300: first divergence at token {np.mean(first):.0f} on average, reference margin there max "
-               f"{max(gaps) if gaps else 0:.3e}, median {np.median(gaps) if gaps else 0:.3e}")
+        report(f"[{name}] teacher-forced logits vs oracle: max abs err {d.max():.3e}, mean {d.mean():.3e}, argmax agreement {agree.mean():.4f}, "
+               f"disagreements at reference margins < {margin[~agree].max() if (~agree).any() else 0:.3e}; free-running 64 rows x 300: first "
+               f"divergence at token {np.mean(first):.0f} on average, reference margin there max {max(gaps) if gaps else 0:.3e}, median "
+               f"{np.median(gaps) if gaps else 0:.3e}")
         assert np.isfinite(lg).all() and (lens == 300).all()
-    assert res["fp8 attention"][0] <= 0.5 and res["fp8 attention"][2] >= 0.85
+        assert d.max() <= ltol, f"{name}: teacher-forced logits {d.max():.3e} from the oracle"
+        assert agree.mean() >= 0.97, f"{name}: argmax agreement {agree.mean():.4f}"
+        assert (margin[~agree] < ltol).all(), f"{name}: argmax differs where the reference's margin exceeds the logit tolerance"
+        assert not gaps or max(gaps) < gtol, f"{name}: a row leaves the reference at a margin of {max(gaps):.3e}"
+
+
+def test_config4_variable_resolution_crops_through_the_fp8_engine():
+    """BASELINE configs[4], both halves together: variable-resolution RGB crops (h, w = round(exp(U(ln 32, ln 512))),
+    SURVEY.md 8(d)) from host memory -> luminance + Pillow-exact resize on the device -> bf16 encoder -> fp8-attention
+    greedy decode, against the CPU oracle fed the same crops through its Pillow restatement (oracle/pil_ops.py): every
+    row identical to the oracle up to its first divergence, which must sit at an oracle margin below FP8_GAP_TOL."""
+    from oracle import pil_ops
+    rs = np.random.RandomState(4321)
+    n, L = 24, 40
+    hw = np.rint(np.exp(rs.uniform(np.log(32), np.log(512), size=(n, 2)))).astype(int)
+    imgs = [rs.randint(0, 256, size=(h, w, 3), dtype=np.uint8) for h, w in hw]
+    eng = engine("bf16", max_batch=64, flags=LATENT_ALWAYS | FP8)
+    ids, lens = eng.recognize_images(imgs)
+    planes = np.stack([pil_ops.preprocess_rgb_to_gray224(im) for im in imgs])
+    np.testing.assert_array_equal(eng.preprocess(imgs), planes)           # the planes the encoder saw
+    o = oracle()
+    want, logits = o.generate(o.encode(o.preprocess_gray(planes)), max_len=L, return_logits=True)
+    srt = np.sort(logits, axis=-1)
+    margin = srt[..., -1] - srt[..., -2]
+    worst, ndiv = 0.0, 0
+    for b in range(n):
+        neq = np.nonzero(ids[b, :L] != want[b, :L])[0]
+        if neq.size:
+            t = int(neq[0])
+            ndiv += 1
+            worst = max(worst, float(margin[b, t - 1]))
+            assert margin[b, t - 1] < FP8_GAP_TOL, f"crop {b} ({hw[b][0]}x{hw[b][1]}) leaves the oracle at token {t}, margin {margin[b, t - 1]:.3e}"
+    report(f"configs[4] on one GPU: {n} variable-resolution RGB crops -> device resize -> fp8-attention engine vs oracle over {L} tokens: "
+           f"{n - ndiv} rows identical, {ndiv} diverge at oracle margins <= {worst:.3e}")
