@@ -1,6 +1,6 @@
 // Probe (gfx950): what does it cost a CU to write a 256 x 256 bf16 output tile (128 KiB, 512-byte row segments of a
 // [M, 2304] matrix), and does the drain run in the background of an MFMA loop?  Build + run on the GPU box:
-//     hipcc --offload-arch=gfx950 -O3 -o gpurun_out/store_probe tools/probe/store_probe.hip && gpurun_out/store_probe
+//     hipcc --offload-arch=gfx950 -O3 -o tools/probe/bin/store_probe tools/probe/store_probe.hip && gpurun_out/store_probe
 // Prints, per configuration, the median over blocks of the cycles per tile iteration and the implied bytes/clk/CU.
 #include <hip/hip_runtime.h>
 #include <algorithm>
