@@ -29,6 +29,7 @@
 #include "kernels_attn.h"
 #include "kernels_decode.h"
 #include "kernels_gemm.h"
+#include "kernels_gemm_pers.h"
 #include "kernels_latent.h"
 #include "kernels_latent8.h"
 #include "kernels_smallm.h"
@@ -351,6 +352,33 @@ void launch_gemm_wide2_t(mocr_engine* e, const GemmParams& p0) {
     HIPCHECK(hipGetLastError());
 }
 
+// The persistent kernel (kernels_gemm_pers.h): one block per CU walks its share of the 256 x 256 tiles.  `blocks` = 0:
+// one block per CU (a multiple of 8, at most one per tile); a test may ask for fewer blocks (longer tile sequences).
+template <int EPI, bool SPLIT_DMA>
+void launch_gemm_pers_t(mocr_engine* e, const GemmParams& p0, int blocks) {
+    GemmParams p = p0;
+    p.ntn = p.N / 256;
+    p.ntm = (p.M + 255) / 256;
+    const int ntiles = p.ntm * p.ntn;
+    int grid = std::min(blocks > 0 ? blocks : e->num_cus, (ntiles + 7) / 8 * 8);
+    grid = std::max(8, grid / 8 * 8);
+    static const int stagger_env = env_int("MOCR_GEMM_STAGGER", 0);
+    p.stagger = stagger_env;
+    hipLaunchKernelGGL((gemm_pers_kernel<EPI, SPLIT_DMA>), dim3(grid), dim3(512), PERS_LDS, e->stream, p);
+    HIPCHECK(hipGetLastError());
+}
+
+template <bool SPLIT_DMA>
+void launch_gemm_pers(mocr_engine* e, const GemmParams& p, int epi, int blocks) {
+    if (p.k_per_split % 64 || p.k_per_split < 128) throw ArgError{"persistent gemm: K must be a multiple of 64, >= 128", MOCR_ERR_ARG};
+    switch (epi) {
+        case EPI_BIAS: launch_gemm_pers_t<EPI_BIAS, SPLIT_DMA>(e, p, blocks); break;
+        case EPI_BIAS_GELU: launch_gemm_pers_t<EPI_BIAS_GELU, SPLIT_DMA>(e, p, blocks); break;
+        case EPI_BIAS_RESID: launch_gemm_pers_t<EPI_BIAS_RESID, SPLIT_DMA>(e, p, blocks); break;
+        default: throw ArgError{"persistent gemm: unsupported epilogue", MOCR_ERR_ARG};
+    }
+}
+
 void launch_gemm_wide2(mocr_engine* e, const GemmParams& p, int epi) {
     if (p.k_per_split % 64 || p.k_per_split < 128) throw ArgError{"wide2 gemm: K must be a multiple of 64, >= 128", MOCR_ERR_ARG};
     switch (epi) {
@@ -401,13 +429,16 @@ void gemm(mocr_engine* e, const char* name, const void* A, int lda, const void* 
     const double bytes = ((double)M * K + (double)N * K) * sizeof(T) + (double)M * N * out_b * (epi == EPI_SLAB ? split : 1) +
                          (epi == EPI_BIAS_RESID ? (double)M * N * 4 : 0);
     ProfScope ps(e, name, 2.0 * M * N * K * ybatch, bytes * ybatch);
-    if (tile == 2048) launch_gemm_wide2(e, p, epi);
+    if (tile == 4096) launch_gemm_pers<true>(e, p, epi, 0);
+    else if (tile == 4097) launch_gemm_pers<true>(e, p, epi, 8);    // test hook: 8 blocks walk all the tiles
+    else if (tile == 4098) launch_gemm_pers<false>(e, p, epi, 0);   // experiment: every wave requests LDS-DMA
+    else if (tile == 2048) launch_gemm_wide2(e, p, epi);
     else if (tile == 1024) launch_gemm_wide<4>(e, p, epi);
     else if (tile == 512) launch_gemm_wide<2>(e, p, epi);
     else if (tile == 256) launch_gemm256(e, p, epi);
     else if (tile == 128) launch_gemm_epi<T, 128, 128>(e, p, epi, split, ybatch);
     else if (tile == 64) launch_gemm_epi<T, 64, 64>(e, p, epi, split, ybatch);
-    else throw ArgError{"gemm tile must be 64, 128, 256, 512, 1024 or 2048", MOCR_ERR_ARG};
+    else throw ArgError{"gemm tile must be 64, 128, 256, 512, 1024, 2048 or 4096", MOCR_ERR_ARG};
 }
 
 // ---------------------------------------------------------------------------------------- encoder
@@ -478,7 +509,11 @@ void run_encoder(mocr_engine* e, const uint8_t* d_gray, int n) {
     auto layer_tile = [&](int N) {
         if (enc_tile_env) return enc_tile_env;
         const long long tiles = (long long)((M + 255) / 256) * (N / 256);
-        return (sizeof(T) == 2 && tiles >= 3LL * e->num_cus) ? 2048 : small_tile(N);
+        // r03: the persistent kernel (tile code 4096, kernels_gemm_pers.h) instead of one 256 x 256 tile per block (2048)
+        static const int big_env = env_int("MOCR_ENC_BIG_TILE", 4096);
+        // from one tile per CU (r02 asked for three rounds of one-tile blocks; a persistent block has no turnover to amortise)
+        static const int big_rounds = env_int("MOCR_ENC_BIG_ROUNDS", 1);
+        return (sizeof(T) == 2 && tiles >= (long long)big_rounds * e->num_cus) ? big_env : small_tile(N);
     };
     // per-GEMM overrides for experiments: MOCR_ENC_TILE_QKV / _O / _FC1 / _FC2 (tile codes as in gemm())
     static const int tq_env = env_int("MOCR_ENC_TILE_QKV", 0), to_env = env_int("MOCR_ENC_TILE_O", 0),
@@ -957,6 +992,12 @@ template <typename T> void init_kernel_attrs() {
     set_max_lds(gemm_wide2_kernel<EPI_BIAS>, 4 * (256 + 256) * 64);
     set_max_lds(gemm_wide2_kernel<EPI_BIAS_GELU>, 4 * (256 + 256) * 64);
     set_max_lds(gemm_wide2_kernel<EPI_BIAS_RESID>, 4 * (256 + 256) * 64);
+    set_max_lds(gemm_pers_kernel<EPI_BIAS, true>, PERS_LDS);
+    set_max_lds(gemm_pers_kernel<EPI_BIAS_GELU, true>, PERS_LDS);
+    set_max_lds(gemm_pers_kernel<EPI_BIAS_RESID, true>, PERS_LDS);
+    set_max_lds(gemm_pers_kernel<EPI_BIAS, false>, PERS_LDS);
+    set_max_lds(gemm_pers_kernel<EPI_BIAS_GELU, false>, PERS_LDS);
+    set_max_lds(gemm_pers_kernel<EPI_BIAS_RESID, false>, PERS_LDS);
     set_max_lds(gemm256_kernel<EPI_BIAS>, l256);
     set_max_lds(gemm256_kernel<EPI_BIAS_GELU>, l256);
     set_max_lds(gemm256_kernel<EPI_BIAS_RESID>, l256);

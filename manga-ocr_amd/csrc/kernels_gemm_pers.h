@@ -1,0 +1,351 @@
+// gemm_pers_kernel: the encoder's layer GEMMs as ONE persistent block per CU (r03).
+//
+// What r02's measurements said about gemm_wide2_kernel at M = 50,432 (one 256 x 256 tile per block, one block per CU):
+//   * the K loop alone runs at 1.3 PF, the whole kernel at 0.43 (O-proj) .. 0.95 PF (QKV): every tile pays a block
+//     turnover (launch, three K-tiles of cold DMA latency) and an epilogue nothing overlaps;
+//   * tools/probe/store_probe.hip (r03): a CU writes a 128 KiB output tile in 1.1 us when it stores alone (50 B/clk) but in
+//     4.3 us when all 256 CUs store at the same moment (7.8 TB/s chip-wide) - and the one-tile-per-block grid makes them
+//     all reach their epilogue together, round after round; stores issued by four of the eight waves drain behind the
+//     other waves' MFMAs at no cost (768 MFMAs per wave: 25.4k -> 25.9k cycles).
+// Here a block walks its whole list of tiles:
+//   * the LDS ring never drains: the K-tile requested at iteration g is K-tile g + 3 of the block's whole sequence, so
+//     the first three K-tiles of tile i + 1 arrive while tile i is multiplied and stored - no cold start per tile, and
+//     the blocks drift apart instead of meeting at every epilogue;
+//   * the global stores of the epilogue are issued by waves 4-7 only (store_probe: four waves' stores drain behind the
+//     MFMAs of all eight), waves 0-3 never have a store in their queue.  Every wave requests its share of the LDS-DMA;
+//     the K loop's counted waits count LOADS only (loads return in issue order; stores are not ordered with older
+//     LDS-DMA on this part), so a store wave's first waits of a tile can at worst hold until its stores
+//     have drained - they cannot end early;
+//   * the epilogue goes through the 64 KiB of LDS that are free at that moment - the slot of the K-tile just consumed
+//     plus the 32 KiB the ring leaves over - in passes of 128 bf16 rows (2 passes) or 64 fp32 rows (4 passes): all eight
+//     waves write their accumulators (bias / GELU / bf16 rounding applied), the store waves read whole rows back and
+//     write 512-byte / 1-KiB row segments.
+// K loop, fragment prefetch across the barrier, swizzles: exactly gemm_wide2_kernel's (kernels_gemm.h).
+#pragma once
+#include "kernels_gemm.h"
+
+// x * Phi(x) with Phi(x) ~ 1 / (1 + exp(-x (a + b x^2 + c x^4))): |error| <= 2.6e-5 against the erf form over the whole
+// line (fitted minimax, tools/fit_gelu.py) - 1/150 of a bf16 half-ulp at |y| ~ 1 - in 9 VALU instructions, two of them
+// transcendental, instead of gelu_fast's 16.  x^2 is clamped at 64 (the odd polynomial turns over at |x| ~ 10; at
+// |x| = 8 the sigmoid already is 0 or 1 in fp32).  Constants carry the -log2(e) of exp2.
+__device__ __forceinline__ float gelu_sig(float x) {
+    const float x2 = fminf(x * x, 64.0f);
+    float t = fmaf(x2, 1.0142628e-3f, -1.0677572e-1f);      // -log2e * (c x^2 + b)
+    t = fmaf(x2, t, -2.3011213f);                            // -log2e * a
+    const float e = __builtin_amdgcn_exp2f(x * t);
+    return x * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+constexpr int PERS_LDS = 160 * 1024;      // four 32 KiB ring slots + 32 KiB that only the epilogue uses
+
+// SPLIT_DMA: the LDS-DMA of a K-tile is requested by waves 0-3 alone (8 pieces each; those waves then never have a
+// store in their queue) instead of by all eight waves (4 pieces each).
+template <int EPI, bool SPLIT_DMA>
+__global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
+    constexpr int BM = 256, BN = 256, WN = 4;
+    constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64, STAGE = A_BYTES + B_BYTES;   // 32 KiB per 32-deep K-tile
+    constexpr int RING = 4 * STAGE;                                                  // 128 KiB; + 32 KiB spare = 160 KiB
+    static_assert(EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID, "epilogues of the encoder layers");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const bool dma_wave = wave < 4;                 // waves 0-3: every global_load_lds; waves 4-7: every global store
+    const int sw = wave - 4;                        // store wave index 0..3 (valid when !dma_wave)
+
+    // this block's tiles: XCD (blockIdx & 7) owns a contiguous chunk of the tile list; its blocks take the chunk's tiles
+    // round-robin, so the tiles in flight on one XCD at any time are neighbours (shared A row-panels / W slices in L2)
+    const int ntiles = p.ntm * p.ntn;
+    int tile, tile_end;
+    const int tstride = gridDim.x >> 3;
+    {
+        const int xcd = blockIdx.x & 7, q = ntiles >> 3, r = ntiles & 7;
+        const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        tile = start + (blockIdx.x >> 3);
+        tile_end = start + (xcd < r ? q + 1 : q);
+    }
+    if (tile >= tile_end) return;
+    // Experiment knob (MOCR_GEMM_STAGGER, x 1024 cycles): the four CUs that are neighbours in an XCD's block order start a
+    // quarter, a half, three quarters of that time apart, so that the chip's blocks do not all reach their epilogues at once
+    if (p.stagger > 0) {
+        const int units = (int)((blockIdx.x >> 3) & 3) * p.stagger / 4;
+        for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(16);
+    }
+    const int nt = p.k_per_split / 32;            // even, >= 4 (checked on the host)
+    const size_t a_row = (size_t)p.lda * 2, w_row = (size_t)p.ldw * 2;
+    const bool guard = (p.M & (BM - 1)) != 0;
+
+    // ---- DMA: piece = 16 rows x 64 B = 1 KiB; wave w requests pieces w, w+8 of the A tile and of the W tile: 4 per
+    // K-tile (r03 measurement: with the eight requests of a K-tile on four waves those waves' issue time - ~35 visible
+    // cycles per request - was the K loop's critical path: +18..30 % over the loop without DMA).
+    // Lane -> row lane>>2 of the piece, logical chunk (lane&3) ^ 2*((row>>3)&1).
+    const int drow = lane >> 2, dchunk = (lane & 3) ^ (((lane >> 5) & 1) << 1);
+    const size_t a_lane = (size_t)(wave * 16 + drow) * a_row + dchunk * 16, w_lane = (size_t)(wave * 16 + drow) * w_row + dchunk * 16;
+    constexpr int NPIECE = SPLIT_DMA ? 4 : 2, PSTEP = SPLIT_DMA ? 4 : 8, LPT = 2 * NPIECE;      // per wave and K-tile: A pieces, W pieces; requests
+    const bool issues_dma = !SPLIT_DMA || dma_wave;
+    int pf_tile = tile, pf_kt = 0;               // the next K-tile to request: (pf_tile, pf_kt), global index pf_g
+    int pf_g = 0;
+    const char* pf_a = nullptr;
+    const char* pf_w = nullptr;
+    auto pf_set = [&]() {
+        int tm, tn;
+        gemm_tile_of(p, pf_tile, tm, tn);
+        if (p.ablate & 16) { tm &= 3; tn = 0; }              // diagnostics: every tile reads the same few (L2-resident) operand panels
+        pf_a = (const char*)p.A + (size_t)(tm * BM) * a_row + a_lane;
+        pf_w = (const char*)p.W + (size_t)(tn * BN) * w_row + w_lane;
+    };
+    pf_set();
+    auto stage_next = [&]() {                    // no-op once the block's last K-tile has been requested
+        if (pf_tile >= tile_end) return;
+        if (!issues_dma) { ++pf_g; if (++pf_kt == nt) { pf_kt = 0; pf_tile += tstride; } return; }
+        if ((p.ablate & 2) && pf_g >= 3) { ++pf_g; if (++pf_kt == nt) { pf_kt = 0; pf_tile += tstride; } return; }      // diagnostics: K loop without DMA
+        char* sa = smem + (pf_g & 3) * STAGE + wave * 1024;
+        const char* ga = pf_a + (size_t)pf_kt * 64;
+        const char* gw = pf_w + (size_t)pf_kt * 64;
+#pragma unroll
+        for (int i = 0; i < NPIECE; ++i) glds16(ga + (size_t)(16 * PSTEP * i) * a_row, sa + i * PSTEP * 1024);
+#pragma unroll
+        for (int i = 0; i < NPIECE; ++i) glds16(gw + (size_t)(16 * PSTEP * i) * w_row, sa + A_BYTES + i * PSTEP * 1024);
+        ++pf_g;
+        if (++pf_kt == nt) {
+            pf_kt = 0;
+            pf_tile += tstride;
+            if (pf_tile < tile_end) pf_set();
+        }
+    };
+
+    const int frag_off = l15 * 64 + ((g4 ^ (((l15 >> 3) & 1) << 1)) << 4);
+    const unsigned offA = lds_addr_of(smem) + (wm * 128) * 64 + frag_off, offB = lds_addr_of(smem) + A_BYTES + (wn * 64) * 64 + frag_off;
+
+    // EPI_BIAS_RESID: the accumulators START as the tile's residual rows (out = resid + A.W^T + bias): the residual is
+    // read in the accumulator layout - lane: 16 bytes of row 16i + l15, columns 16j + 4 g4 - for tile i + 1 while tile i's
+    // epilogue runs, m-tile by m-tile as the epilogue hands the registers back, so no load sits in front of a store of the
+    // epilogue and the read hides behind the other passes (r03: read by the store waves inside the epilogue, eight rows at
+    // a time, it cost 27 us per tile).  fp32 sums: the products are added onto the residual instead of the other way
+    // round - a reordering of one fp32 addition per 32 products, ~1e-7 relative.
+    f32x4 acc[4][8];
+    auto load_resid = [&](int tl, int i) {       // m-tile i of tile tl -> acc[.][i]
+        int tm_, tn_;
+        gemm_tile_of(p, tl, tm_, tn_);
+        int m = tm_ * BM + wm * 128 + 16 * i + l15;
+        if (guard && m >= p.M) m = p.M - 1;      // rows behind M: any finite values (never stored)
+        const float* src = p.resid + (size_t)m * p.ldo + tn_ * BN + wn * 64 + 4 * g4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j][i] = *reinterpret_cast<const f32x4*>(src + 16 * j);
+    };
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if constexpr (EPI == EPI_BIAS_RESID) load_resid(tile, i);
+        else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+
+    int g = 0;                                   // global index of the K-tile being multiplied
+    stage_next(); stage_next(); stage_next();
+    if (issues_dma) wait_vmcnt<2 * LPT>();       // K-tile 0 (own pieces); K-tiles 1 and 2 stay in flight
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    WideFrags P, Q;
+    MOCR_W2_READ_HEAD(P, offA, offB);
+
+    // one K-tile: CUR holds its first six fragments (requested during the previous K-tile), NXT receives those of the next
+#define MOCR_PERS_KTILE(CUR, NXT)                                                                                      \
+    {                                                                                                                  \
+        const unsigned so = (unsigned)((g & 3) * STAGE), sn = (unsigned)(((g + 1) & 3) * STAGE);                        \
+        MOCR_W2_READ_TAIL(CUR, offA + so);                                                                             \
+        stage_next();                                     /* K-tile g + 3 into the slot of K-tile g - 1 */              \
+        asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(CUR.fb[0]), "+v"(CUR.fb[1]), "+v"(CUR.fb[2]), "+v"(CUR.fb[3]),      \
+                     "+v"(CUR.fa[0]), "+v"(CUR.fa[1]));                                                                \
+        MOCR_W2_GROUP(CUR, 0);                                                                                         \
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(CUR.fa[2]), "+v"(CUR.fa[3]));                                       \
+        MOCR_W2_GROUP(CUR, 1);                                                                                         \
+        /* every fragment of this K-tile is in registers: its slot may be refilled behind the next barrier */         \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(CUR.fa[4]), "+v"(CUR.fa[5]), "+v"(CUR.fa[6]), "+v"(CUR.fa[7]));     \
+        {                                                                                                              \
+            /* K-tile g + 1 landed (own pieces); the K-tiles requested after it stay in flight.  N counts LOADS only:  \
+               loads (DMA or ordinary) return in issue order, so with at most N operations outstanding the pieces of  \
+               K-tile g + 1 cannot be among them - whatever the stores of a store wave's last epilogue are doing (they \
+               are OLDER than the newest DMA: the wait may hold until they have drained, it can never end early). */   \
+            const int ahead = pf_g - g - 2;                                                                            \
+            if (issues_dma) {                                                                                          \
+                if (ahead >= 2) wait_vmcnt<2 * LPT>(); else if (ahead == 1) wait_vmcnt<LPT>(); else wait_vmcnt<0>();   \
+            }                                                                                                          \
+        }                                                                                                              \
+        __builtin_amdgcn_s_barrier();                                                                                  \
+        asm volatile("" ::: "memory");                                                                                 \
+        MOCR_W2_READ_HEAD(NXT, offA + sn, offB + sn);                                                                  \
+        MOCR_W2_GROUP(CUR, 2);                                                                                         \
+        MOCR_W2_GROUP(CUR, 3);                                                                                         \
+        ++g;                                                                                                           \
+    }
+
+    for (; tile < tile_end; tile += tstride) {
+        int tm, tn;
+        gemm_tile_of(p, tile, tm, tn);
+        const int m0 = tm * BM, n0 = tn * BN;
+        // bias of this lane's 16 columns: requested here, used in the epilogue (a load in front of the K loop instead of
+        // a round trip in the epilogue)
+        // (EPI_BIAS_RESID: every register counts there - the bias is added by the store waves instead, to whole rows: a
+        // lane then needs the four values of its own columns only)
+        float bias[4][4];
+        float4 bias_row = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (EPI == EPI_BIAS_RESID) {
+            if (!dma_wave) bias_row = *reinterpret_cast<const float4*>(p.bias + n0 + 4 * lane);
+        } else {
+            const float* bsrc = p.bias + n0 + wn * 64 + 4 * g4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 bv = *reinterpret_cast<const float4*>(bsrc + 16 * j);
+                bias[j][0] = bv.x; bias[j][1] = bv.y; bias[j][2] = bv.z; bias[j][3] = bv.w;
+            }
+        }
+        for (int t = 0; t < nt; t += 2) {
+            MOCR_PERS_KTILE(P, Q)
+            MOCR_PERS_KTILE(Q, P)
+        }
+        // ------------------------------------------------------------------------------------------ epilogue of `tile`
+        // LDS free right now: the slot of the K-tile just multiplied, (g - 1) & 3 (every wave passed that K-tile's barrier
+        // with all its fragments in registers), and the spare 32 KiB.  K-tiles g, g + 1, g + 2 of the NEXT tile sit in the
+        // other three slots (landed / in flight); P holds the first six fragments of K-tile g already.
+        if (p.ablate & 4) {                      // diagnostics: no epilogue
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { asm volatile("" :: "v"(acc[j][i])); acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            continue;
+        }
+        // (the row stride is laundered per tile: hipcc otherwise hoists every row's `row * ldo` out of the tile loop - 17
+        // loop-invariant 64-bit offsets it then has to spill)
+        int ldo = p.ldo;
+        asm volatile("" : "+s"(ldo));
+        char* const piece0 = smem + RING;
+        char* const piece1 = smem + ((g - 1) & 3) * STAGE;
+        if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
+            // two passes of 128 rows x 512 B: pass h takes rows 64h .. 64h+63 of each wave's 128 (m-tiles 4h .. 4h+3);
+            // staging row sr = 64 wm + (row within the 64): rows 0-63 in piece0, 64-127 in piece1;
+            // 16-byte chunk c of staging row sr at chunk c ^ (sr & 15)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {
+                    const int i = 4 * h + ii;
+                    const int srl = 16 * ii + l15;                      // row within this wave's piece
+                    char* const base = (wm ? piece1 : piece0) + srl * 512;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float v[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            v[r] = acc[j][i][r] + bias[j][r];
+                            if constexpr (EPI == EPI_BIAS_GELU) { if (!(p.ablate & 32)) v[r] = gelu_sig(v[r]); }
+                            acc[j][i][r] = 0.f;
+                        }
+                        uint2 u;
+                        u.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+                        u.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+                        const int chunk = wn * 8 + 2 * j + (g4 >> 1);
+                        *reinterpret_cast<uint2*>(base + ((chunk ^ (srl & 15)) << 4) + (g4 & 1) * 8) = u;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // staged (a __syncthreads() would drain the DMA waves' ring)
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (!dma_wave) {
+                    // store wave sw reads staging rows 32 sw .. 32 sw + 31, two rows (2 x 512 B) per wave instruction
+                    const int rsel = lane >> 5, lc = lane & 31;
+                    bf16_t* const obase = reinterpret_cast<bf16_t*>(p.out) + (size_t)m0 * ldo + n0 + 8 * lc;
+                    // two halves of eight instructions (32 registers of staged data at a time); the barrier that hands the
+                    // staging area back sits behind the LAST read, in front of the second half's stores
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+                        uint4 v[8];
+#pragma unroll
+                        for (int it = 0; it < 8; ++it) {
+                            const int sr = 32 * sw + 16 * hf + 2 * it + rsel;
+                            const char* src = (sr < 64 ? piece0 : piece1) + (sr & 63) * 512;
+                            v[it] = *reinterpret_cast<const uint4*>(src + ((lc ^ (sr & 15)) << 4));
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        if (hf == 1) {
+                            __builtin_amdgcn_s_barrier();                // read back: the staging area may be rewritten
+                            asm volatile("" ::: "memory");
+                        }
+#pragma unroll
+                        for (int it = 0; it < 8; ++it) {
+                            const int sr = 32 * sw + 16 * hf + 2 * it + rsel;
+                            const int row = (sr >> 6) * 128 + 64 * h + (sr & 63);
+                            // non-temporal: the QKV / FC1 output passes through once (r02: +4 % on the encoder)
+                            if ((!guard || m0 + row < p.M) && !(p.ablate & 8)) st16_nt(obase + (size_t)row * ldo, v[it]);
+                        }
+                    }
+                } else {
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                }
+            }
+        } else {
+            // fp32 (the residual is already in the sums): four passes of 64 rows x 1 KiB: pass q takes m-tiles 2q, 2q+1 (32
+            // rows) of each wave; staging row sr = 32 wm + (row within the 32): rows 0-31 in piece0, 32-63 in piece1;
+            // 16-byte chunk c (0..63) of staging row sr at chunk c ^ (sr & 15)
+            const int nxt = tile + tstride;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii) {
+                    const int i = 2 * q + ii;
+                    const int srl = 16 * ii + l15;
+                    char* const base = (wm ? piece1 : piece0) + srl * 1024;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int chunk = wn * 16 + 4 * j + g4;
+                        *reinterpret_cast<f32x4*>(base + ((chunk ^ (srl & 15)) << 4)) = acc[j][i];
+                    }
+                }
+                // these two m-tiles' registers are free: the next tile's residual rows go there (requested BEFORE this
+                // pass's stores; used by the first MFMAs of the next tile)
+                if (nxt < tile_end) { load_resid(nxt, 2 * q); load_resid(nxt, 2 * q + 1); }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (!dma_wave) {
+                    // store wave sw: staging rows 16 sw .. 16 sw + 15, one 1-KiB row per wave instruction, in two halves of
+                    // eight; the barrier that hands the staging area back sits behind the LAST read
+                    float* const obase = reinterpret_cast<float*>(p.out) + (size_t)m0 * ldo + n0 + 4 * lane;
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+                        float4 v[8];
+#pragma unroll
+                        for (int it = 0; it < 8; ++it) {
+                            const int sr = 16 * sw + 8 * hf + it;
+                            const char* src = (sr < 32 ? piece0 : piece1) + (sr & 31) * 1024;
+                            v[it] = *reinterpret_cast<const float4*>(src + ((lane ^ (sr & 15)) << 4));
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        if (hf == 1) {
+                            __builtin_amdgcn_s_barrier();                // read back: the staging area may be rewritten
+                            asm volatile("" ::: "memory");
+                        }
+#pragma unroll
+                        for (int it = 0; it < 8; ++it) {
+                            const int sr = 16 * sw + 8 * hf + it;
+                            const int row = (sr >> 5) * 128 + 32 * q + (sr & 31);
+                            if ((!guard || m0 + row < p.M) && !(p.ablate & 8))
+                                *reinterpret_cast<float4*>(obase + (size_t)row * ldo) =
+                                    make_float4(v[it].x + bias_row.x, v[it].y + bias_row.y, v[it].z + bias_row.z, v[it].w + bias_row.w);
+                        }
+                    }
+                } else {
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                }
+            }
+        }
+    }
+#undef MOCR_PERS_KTILE
+    // the reads requested behind the last barrier: landed before their registers are used for anything else
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(P.fb[0]), "+v"(P.fb[1]), "+v"(P.fb[2]), "+v"(P.fb[3]), "+v"(P.fa[0]), "+v"(P.fa[1]));
+}

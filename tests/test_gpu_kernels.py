@@ -59,7 +59,7 @@ def test_gemm_epilogues(dtype, tile, M, N, K, epi):
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 768), (700, 2304, 768), (1000, 768, 3072), (256, 768, 256), (300, 512, 128)])
 @pytest.mark.parametrize("epi", [EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_BIAS_F32])
-@pytest.mark.parametrize("tile", [256, 512, 1024, 2048])
+@pytest.mark.parametrize("tile", [256, 512, 1024, 2048, 4096, 4097])
 def test_gemm_256x128_three_stage_ring(M, N, K, epi, tile):
     """The big-tile encoder kernels (bf16 only; 256 = 64-deep K-tiles, epilogue through LDS; 512 = the
     "wide" kernel: 32-deep K-tiles, two blocks per CU, epilogue from the registers): K from 1 to 96
@@ -67,9 +67,9 @@ def test_gemm_256x128_three_stage_ring(M, N, K, epi, tile):
     256 exercises the row guard."""
     if tile >= 512 and epi == EPI_BIAS_F32:
         pytest.skip("the wide kernel has the encoder layers' epilogues only")
-    if tile == 2048 and K < 128:
-        pytest.skip("the four-stage wide kernel (tile code 2048: fragments requested across the K-tile barrier) needs >= 4 K-tiles")
-    if tile != 2048 and K == 128:
+    if tile >= 2048 and K < 128:
+        pytest.skip("the four-stage wide kernels (tile codes 2048 / 4096: fragments requested across the K-tile barrier) need >= 4 K-tiles")
+    if tile < 2048 and K == 128:
         pytest.skip("shape added for the four-stage kernel's shortest K loop")
     eng = engine("bf16")
     rs = np.random.RandomState(M + N + K + epi)
@@ -94,6 +94,41 @@ def test_gemm_256x128_three_stage_ring(M, N, K, epi, tile):
     tol = 1e-5 if out_f32 else 6e-3
     report(f"gemm tile{tile} M{M} N{N} K{K} epi{epi}: max rel err {err:.3e} (tol {tol:.1e})")
     assert np.isfinite(got).all() and err <= tol
+
+
+@pytest.mark.parametrize("epi", [EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID])
+@pytest.mark.parametrize("tile,M,N,K", [(4096, 8900, 2304, 768), (4097, 2500, 768, 3072), (4097, 1300, 3072, 128), (4096, 33000, 768, 768)])
+def test_gemm_persistent_blocks_walk_several_tiles(epi, tile, M, N, K):
+    """gemm_pers_kernel (tile code 4096; 4097 = the same kernel on 8 blocks): a block multiplies a SEQUENCE of 256 x 256
+    tiles - the LDS ring runs across tile boundaries, the epilogue is staged through the slot the last K-tile left, and
+    only four of the eight waves touch global memory - so shapes with more tiles than blocks are what tests it: 315 tiles
+    on 256 blocks, 30 / 72 tiles on 8 blocks (3-9 tiles per block, K loops of 4 and 96 K-tiles), 387 tiles of N = 768.
+    Every output element is checked against float64."""
+    eng = engine("bf16")
+    rs = np.random.RandomState(M + N + K + epi)
+    Mp = (M + 255) // 256 * 256
+    A = bf16_round(rs.standard_normal((Mp, K)).astype(np.float32))
+    W = bf16_round((rs.standard_normal((N, K)) * 0.05).astype(np.float32))
+    bias = rs.standard_normal(N).astype(np.float32)
+    resid = rs.standard_normal((M, N)).astype(np.float32) if epi == EPI_BIAS_RESID else None
+    ref = A[:M].astype(np.float64) @ W.astype(np.float64).T + bias
+    if epi == EPI_BIAS_GELU:
+        ref = _gelu(ref)
+    if epi == EPI_BIAS_RESID:
+        ref = ref + resid
+    out_f32 = epi == EPI_BIAS_RESID
+    dO = torch.full((M + 3, N), float("nan"), device="cuda", dtype=torch.float32 if out_f32 else torch.bfloat16)   # 3 guard rows behind the output
+    dR = torch.from_numpy(resid).cuda() if resid is not None else None
+    dA, dW, dB = _dev(A, "bf16"), _dev(W, "bf16"), torch.from_numpy(bias).cuda()
+    torch.cuda.synchronize()
+    for rep in range(2):                      # twice: the second launch finds the caches warm and the blocks in another phase
+        eng.op_gemm(dA, dW, dB, dO, dR, M, N, K, epi, tile=tile, split_k=1)
+        got = dO.float().cpu().numpy().astype(np.float64)
+        assert np.isnan(got[M:]).all(), "rows behind M were written"
+        err = np.abs(got[:M] - ref).max() / np.abs(ref).max()
+        tol = 1e-5 if out_f32 else 6e-3
+        assert np.isfinite(got[:M]).all() and err <= tol, f"rep {rep}: max rel err {err:.3e}"
+    report(f"persistent gemm tile{tile} M{M} N{N} K{K} epi{epi}: max rel err {err:.3e} (tol {tol:.1e})")
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
