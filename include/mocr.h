@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MOCR_ABI_VERSION 1
+#define MOCR_ABI_VERSION 2      /* 2: mocr_image.rotate (occupies what was padding: the struct keeps its size) */
 
 enum {
     MOCR_OK = 0,
@@ -58,7 +58,7 @@ enum {
     MOCR_FLAG_LATENT_ALWAYS = 1 << 6,     /* bf16: latent attention for every batch size (default: batches of <= 384 rows take the
                                            * classic projected-K/V kernels, whose grid - one block per (row, head) - has half the
                                            * step latency there: 50 instead of 80 ms for 64 crops) */
-    MOCR_FLAG_NO_SMALL_BATCH_PATH = 1 << 8 /* bf16: batches of <= 64 rows through the generic split-K projections + add/LayerNorm
+    MOCR_FLAG_NO_SMALL_BATCH_PATH = 1 << 8 /* bf16: batches of <= 32 rows through the generic split-K projections + add/LayerNorm
                                            * launches (28 per decode step) instead of the one-launch-per-projection path (19) */
 };
 
@@ -125,7 +125,14 @@ typedef struct mocr_image {
     int32_t height, width;
     int64_t row_stride;
     int32_t channels;   /* 1 = L, 3 = RGB, MOCR_CHANNELS_BGR = 3 bytes per pixel in OpenCV's B,G,R order */
+    int32_t rotate;     /* MOCR_ROTATE_NONE, or the reference's orientation-only rotation applied ON THE DEVICE before the
+                         * resize: MOCR_ROTATE_90_CW = cv2.ROTATE_90_CLOCKWISE ("Vertical" setting, landscape crop),
+                         * MOCR_ROTATE_90_CCW = cv2.ROTATE_90_COUNTERCLOCKWISE ("Horizontal" setting, portrait crop);
+                         * src/core/workers.py:320-326, src/ui/main_window.py:9787-9795.  height / width / row_stride
+                         * describe the crop as it lies in memory (before the rotation).  Ignored for pages of
+                         * mocr_recognize_regions. */
 } mocr_image;
+enum { MOCR_ROTATE_NONE = 0, MOCR_ROTATE_90_CW = 1, MOCR_ROTATE_90_CCW = 2 };
 /* BGR pixels as the reference's crop tools and pages hold them (`cropped_cv_img`, `cv_image`: src/ui/main_window.py:6431,
  * src/core/workers.py:461): the BGR -> RGB swap of src/ui/main_window.py:9800 is folded into the luminance conversion. */
 #define MOCR_CHANNELS_BGR (-3)

@@ -13,6 +13,10 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <exception>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -30,6 +34,9 @@
 #include "kernels_decode.h"
 #include "kernels_gemm.h"
 #include "kernels_gemm_pers.h"
+#ifdef MOCR_EXPERIMENTS
+#include "kernels_gemm_lab.h"      // A/B kernels of earlier rounds: not in the product library
+#endif
 #include "kernels_latent.h"
 #include "kernels_latent8.h"
 #include "kernels_smallm.h"
@@ -114,6 +121,7 @@ struct LaneCtx {
 
 // One recognise request of <= max_batch crops.
 struct Job {
+    hipEvent_t wait_ev = nullptr;   // device planes that a preparation stream is still writing: the lane's stream waits for this first
     const uint8_t* src = nullptr;   // host images (src_host) or device luminance planes
     bool src_host = false;
     int channels = 1;
@@ -140,7 +148,7 @@ struct mocr_engine : LaneCtx {
     std::string err;
     std::mutex mu;
     std::mutex err_mu;              // guards err: mocr_last_error may be called while another thread fails
-    bool poisoned = false;          // a HIP call failed: HIP errors are sticky, so every later call is refused
+    std::atomic<bool> poisoned{false};   // a HIP call failed: HIP errors are sticky, so every later call is refused (read without the mutex)
     bool committed = false;
     int gen_max_len = 0;            // generate(max_length) of the device-buffer submissions (mocr_set_generate_max_length)
     bool fp8attn = false;           // latent attention on e4m3 key/value rows + fp8 MFMA (MOCR_FLAG_FP8_ATTENTION, opt-in)
@@ -168,16 +176,20 @@ struct mocr_engine : LaneCtx {
     std::map<int, ResampleTable> rs_tables;
     struct Scratch { void* p = nullptr; size_t cap = 0; };
     Scratch rs_src, rs_tmp, rs_desc, rs_coef, rs_bounds, rs_gray;
-    Scratch rs_pin;          // PINNED host staging of the packed pixel rows (grow-only): the H2D copy is one DMA at link speed
-    void* grow_pinned(size_t bytes) {
-        if (bytes > rs_pin.cap) {
-            if (rs_pin.p) HIPCHECK(hipHostFree(rs_pin.p));
-            rs_pin.p = nullptr; rs_pin.cap = 0;
+    // PINNED host staging of the packed pixel rows (grow-only): the H2D copy is one DMA at link speed.  Two buffers: the
+    // host packs chunk k + 1 into one while the copy engine reads chunk k from the other (prepare_and_decode).
+    Scratch rs_pin[2];
+    hipStream_t prep_stream = nullptr;      // pack -> H2D -> resize of the host entry points: never a lane's stream
+    void* grow_pinned(int slot, size_t bytes) {
+        Scratch& sp = rs_pin[slot & 1];
+        if (bytes > sp.cap) {
+            if (sp.p) HIPCHECK(hipHostFree(sp.p));
+            sp.p = nullptr; sp.cap = 0;
             const size_t cap = std::max<size_t>(bytes + bytes / 2, 1 << 20);
-            HIPCHECK(hipHostMalloc(&rs_pin.p, cap, hipHostMallocDefault));
-            rs_pin.cap = cap;
+            HIPCHECK(hipHostMalloc(&sp.p, cap, hipHostMallocDefault));
+            sp.cap = cap;
         }
-        return rs_pin.p;
+        return sp.p;
     }
     void* grow(Scratch& s, size_t bytes) {
         if (bytes > s.cap) {
@@ -251,11 +263,17 @@ struct ProfScope {
     ~ProfScope() { e->prof_end(); }
 };
 
-// Tuning knobs (environment overrides are for experiments; defaults are the measured best).
+// Tuning knobs: the MOCR_* environment overrides exist in the experiments build only (-DMOCR_EXPERIMENTS,
+// `python manga-ocr_amd/build.py --experiments`, used by tools/); the product library runs the measured defaults and
+// reads no environment variable in its launch code.
+#ifdef MOCR_EXPERIMENTS
 static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return (v && *v) ? atoi(v) : dflt;
 }
+#else
+static constexpr int env_int(const char*, int dflt) { return dflt; }
+#endif
 
 template <typename K> void set_max_lds(K kernel, int bytes) {
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
@@ -301,6 +319,7 @@ void launch_gemm_epi(mocr_engine* e, const GemmParams& p, int epi, int split, in
     }
 }
 
+#ifdef MOCR_EXPERIMENTS
 template <int EPI>
 void launch_gemm256_t(mocr_engine* e, const GemmParams& p0) {
     GemmParams p = p0;
@@ -342,15 +361,14 @@ void launch_gemm_wide2_t(mocr_engine* e, const GemmParams& p0) {
     p.ntn = p.N / 256;
     p.ntm = (p.M + 255) / 256;
     const int grid = (p.ntm * p.ntn + 7) / 8 * 8;
-    // stagger: one tile's duration in units of 1024 cycles: ~1100 cycles per 32-deep K-tile plus the epilogue
     static const int stagger_env = env_int("MOCR_GEMM_STAGGER", -1);
-    const int tile_units = (p.k_per_split / 32) * 1100 / 1024 + 8;
-    (void)tile_units;
     p.stagger = stagger_env > 0 ? stagger_env : 0;      // measured r02: no gain (the store drain is not what a phase shift hides), default off
     p.first_round = e->num_cus;
     hipLaunchKernelGGL((gemm_wide2_kernel<EPI>), dim3(grid), dim3(512), 4 * (256 + 256) * 64, e->stream, p);
     HIPCHECK(hipGetLastError());
 }
+
+#endif  // MOCR_EXPERIMENTS
 
 // The persistent kernel (kernels_gemm_pers.h): one block per CU walks its share of the 256 x 256 tiles.  `blocks` = 0:
 // one block per CU (a multiple of 8, at most one per tile); a test may ask for fewer blocks (longer tile sequences).
@@ -379,6 +397,7 @@ void launch_gemm_pers(mocr_engine* e, const GemmParams& p, int epi, int blocks) 
     }
 }
 
+#ifdef MOCR_EXPERIMENTS
 void launch_gemm_wide2(mocr_engine* e, const GemmParams& p, int epi) {
     if (p.k_per_split % 64 || p.k_per_split < 128) throw ArgError{"wide2 gemm: K must be a multiple of 64, >= 128", MOCR_ERR_ARG};
     switch (epi) {
@@ -399,7 +418,10 @@ void launch_gemm_wide(mocr_engine* e, const GemmParams& p, int epi) {
     }
 }
 
-// A [M,K] (lda), W [N,K] (ldw=K), out (ldo).  tile: 64, 128, 256 (256x128, 3-stage), 512 (the "wide" 256x128 kernel) or 1024 (wide, 256x256, 8 waves) (= the 256x128 bf16 kernel).
+#endif  // MOCR_EXPERIMENTS
+
+// A [M,K] (lda), W [N,K] (ldw=K), out (ldo).  tile: 64 / 128 (gemm_kernel), 4096 (the persistent 256 x 256 encoder kernel;
+// 4097: the same on 8 blocks, a test hook); experiments build only: 256, 512, 1024, 2048, 4098 (kernels_gemm_lab.h).
 // split > 1 only with EPI_SLAB.
 struct HeadBatch { int heads = 1; long long a_yoff = 0, w_yoff = 0, o_yoff = 0, b_yoff = 0; int ldw = 0; };
 
@@ -408,7 +430,7 @@ void gemm(mocr_engine* e, const char* name, const void* A, int lda, const void* 
           const float* resid, int M, int N, int K, int epi, int tile, int split, long long slab_stride = 0,
           const float* pos = nullptr, int patches = 0, const HeadBatch* hb = nullptr, int group_n = 0, int* cand_idx = nullptr) {
     const int kt = 128 / (int)sizeof(T);
-    if (N % (tile >= 1024 ? 256 : tile >= 256 ? 128 : tile) || K % (kt * split) || (split > 1 && epi != EPI_SLAB) ||
+    if (N % (tile >= 1024 ? 256 : tile >= 256 ? 128 : std::max(tile, 1)) || K % (kt * split) || (split > 1 && epi != EPI_SLAB) ||
         (tile >= 256 && (sizeof(T) != 2 || split != 1)))
         throw ArgError{std::string("gemm shape not tileable: ") + name, MOCR_ERR_ARG};
     GemmParams p{};
@@ -431,14 +453,19 @@ void gemm(mocr_engine* e, const char* name, const void* A, int lda, const void* 
     ProfScope ps(e, name, 2.0 * M * N * K * ybatch, bytes * ybatch);
     if (tile == 4096) launch_gemm_pers<true>(e, p, epi, 0);
     else if (tile == 4097) launch_gemm_pers<true>(e, p, epi, 8);    // test hook: 8 blocks walk all the tiles
+#ifdef MOCR_EXPERIMENTS
     else if (tile == 4098) launch_gemm_pers<false>(e, p, epi, 0);   // experiment: every wave requests LDS-DMA
     else if (tile == 2048) launch_gemm_wide2(e, p, epi);
     else if (tile == 1024) launch_gemm_wide<4>(e, p, epi);
     else if (tile == 512) launch_gemm_wide<2>(e, p, epi);
     else if (tile == 256) launch_gemm256(e, p, epi);
+#else
+    else if (tile == 256 || tile == 512 || tile == 1024 || tile == 2048 || tile == 4098)
+        throw ArgError{"this GEMM tile code is an A/B kernel of the experiments build (build.py --experiments)", MOCR_ERR_UNSUPPORTED};
+#endif
     else if (tile == 128) launch_gemm_epi<T, 128, 128>(e, p, epi, split, ybatch);
     else if (tile == 64) launch_gemm_epi<T, 64, 64>(e, p, epi, split, ybatch);
-    else throw ArgError{"gemm tile must be 64, 128, 256, 512, 1024, 2048 or 4096", MOCR_ERR_ARG};
+    else throw ArgError{"gemm tile must be 64, 128 or 4096", MOCR_ERR_ARG};
 }
 
 // ---------------------------------------------------------------------------------------- encoder
@@ -511,8 +538,9 @@ void run_encoder(mocr_engine* e, const uint8_t* d_gray, int n) {
         const long long tiles = (long long)((M + 255) / 256) * (N / 256);
         // r03: the persistent kernel (tile code 4096, kernels_gemm_pers.h) instead of one 256 x 256 tile per block (2048)
         static const int big_env = env_int("MOCR_ENC_BIG_TILE", 4096);
-        // from one tile per CU (r02 asked for three rounds of one-tile blocks; a persistent block has no turnover to amortise)
-        static const int big_rounds = env_int("MOCR_ENC_BIG_ROUNDS", 1);
+        // from two tiles per CU (r02 asked for three rounds of one-tile blocks; a persistent block has no turnover to
+        // amortise, and at batch 256 the N = 768 GEMMs have 591 tiles)
+        static const int big_rounds = env_int("MOCR_ENC_BIG_ROUNDS", 2);
         return (sizeof(T) == 2 && tiles >= (long long)big_rounds * e->num_cus) ? big_env : small_tile(N);
     };
     // per-GEMM overrides for experiments: MOCR_ENC_TILE_QKV / _O / _FC1 / _FC2 (tile codes as in gemm())
@@ -934,7 +962,8 @@ void run_cross_kv(mocr_engine* e, int n) {
     const int M = n * e->S;
     static const int enc_tile_env = env_int("MOCR_ENC_TILE", 0);
     const bool few_blocks = (long long)((M + 127) / 128) * (e->NCKV / 128) * 5 <= 4LL * e->num_cus;      // see run_encoder
-    const int ET = enc_tile_env ? enc_tile_env : ((sizeof(T) == 2 && M >= 256 * 48) ? 256 : few_blocks ? 64 : 128);
+    const bool big = sizeof(T) == 2 && (long long)((M + 255) / 256) * (e->NCKV / 256) >= e->num_cus && e->NCKV % 256 == 0;
+    const int ET = enc_tile_env ? enc_tile_env : big ? 4096 : few_blocks ? 64 : 128;
     gemm<T>(e, "gemm_cross_kv", e->ENC, e->D, e->w.wckv, e->w.bckv, e->CKV, e->NCKV, nullptr, M, e->NCKV, e->D,
             EPI_BIAS, ET, 1);
 }
@@ -982,6 +1011,7 @@ template <typename T> void init_kernel_attrs() {
     set_max_lds(enc_attn_simple_kernel<T>, (200 * 65 + 200 * 64 + 4 * 64 + 4 * 256) * 4);
     set_max_lds(enc_attn_mfma_kernel, ENC_SP * 128 + 64 * ENC_VT_LD * 2);
     set_max_lds(dec_qqt_kernel, 160 * 1024);
+#ifdef MOCR_EXPERIMENTS
     constexpr int l256 = 3 * (256 + 128) * 128;
     set_max_lds(gemm_wide_kernel<EPI_BIAS, 2>, 3 * (256 + 128) * 64);
     set_max_lds(gemm_wide_kernel<EPI_BIAS_GELU, 2>, 3 * (256 + 128) * 64);
@@ -992,9 +1022,11 @@ template <typename T> void init_kernel_attrs() {
     set_max_lds(gemm_wide2_kernel<EPI_BIAS>, 4 * (256 + 256) * 64);
     set_max_lds(gemm_wide2_kernel<EPI_BIAS_GELU>, 4 * (256 + 256) * 64);
     set_max_lds(gemm_wide2_kernel<EPI_BIAS_RESID>, 4 * (256 + 256) * 64);
+#endif
     set_max_lds(gemm_pers_kernel<EPI_BIAS, true>, PERS_LDS);
     set_max_lds(gemm_pers_kernel<EPI_BIAS_GELU, true>, PERS_LDS);
     set_max_lds(gemm_pers_kernel<EPI_BIAS_RESID, true>, PERS_LDS);
+#ifdef MOCR_EXPERIMENTS
     set_max_lds(gemm_pers_kernel<EPI_BIAS, false>, PERS_LDS);
     set_max_lds(gemm_pers_kernel<EPI_BIAS_GELU, false>, PERS_LDS);
     set_max_lds(gemm_pers_kernel<EPI_BIAS_RESID, false>, PERS_LDS);
@@ -1003,6 +1035,7 @@ template <typename T> void init_kernel_attrs() {
     set_max_lds(gemm256_kernel<EPI_BIAS_RESID>, l256);
     set_max_lds(gemm256_kernel<EPI_PATCH>, l256);
     set_max_lds(gemm256_kernel<EPI_BIAS_F32>, l256);
+#endif
     set_max_lds(smallm_gemm_kernel<SM_PRO_LN, SM_EPI_RAW, 2, 3>, SM_LDS(SM_PRO_LN, 2));
     set_max_lds(smallm_gemm_kernel<SM_PRO_LN, SM_EPI_GELU_BF16, 2, 3>, SM_LDS(SM_PRO_LN, 2));
     set_max_lds(smallm_gemm_kernel<SM_PRO_LN, SM_EPI_GELU_F32, 2, 3>, SM_LDS(SM_PRO_LN, 2));
@@ -1088,6 +1121,7 @@ void start_batch(mocr_engine* e, Lane& L) {
     int row0 = 0;
     for (const Job& j : L.jobs) {
         uint8_t* gdst = e->d_in + (size_t)row0 * plane;
+        if (j.wait_ev) HIPCHECK(hipStreamWaitEvent(e->stream, j.wait_ev, 0));
         if (!j.src_host) {
             HIPCHECK(hipMemcpyAsync(gdst, j.src, plane * j.n, hipMemcpyDeviceToDevice, e->stream));
         } else {
@@ -1479,6 +1513,7 @@ void allocate_lanes(mocr_engine* e) {
         HIPCHECK(hipEventCreateWithFlags(&e->lanes[i].flag_ev[1], hipEventDisableTiming));
     }
     e->bind(0);
+    HIPCHECK(hipStreamCreateWithFlags(&e->prep_stream, hipStreamNonBlocking));
 }
 
 static void set_error(mocr_engine* e, const std::string& msg) {
@@ -1488,7 +1523,7 @@ static void set_error(mocr_engine* e, const std::string& msg) {
 
 template <typename F> int guarded(mocr_engine* e, F&& f) {
     if (!e) return MOCR_ERR_ARG;
-    if (e->poisoned) {
+    if (e->poisoned.load(std::memory_order_acquire)) {
         // after a failed HIP call (a fault, a lost device) the context is not trustworthy and HIP keeps
         // returning the same error: refuse instead of serving from a half-dead engine
         return MOCR_ERR_STATE;
@@ -1501,7 +1536,7 @@ template <typename F> int guarded(mocr_engine* e, F&& f) {
         snprintf(buf, sizeof(buf), "HIP error %d (%s) at engine.hip:%d: %s - the engine refuses further calls (MOCR_ERR_STATE) until it is destroyed",
                  (int)h.code, hipGetErrorString(h.code), h.line, h.what);
         set_error(e, buf);
-        e->poisoned = true;
+        e->poisoned.store(true, std::memory_order_release);
         return MOCR_ERR_HIP;
     } catch (const ArgError& a) {
         set_error(e, a.msg);
@@ -1575,7 +1610,9 @@ void mocr_destroy(mocr_engine* e) {
     for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
     for (auto* sc : {&e->rs_src, &e->rs_tmp, &e->rs_desc, &e->rs_coef, &e->rs_bounds, &e->rs_gray})
         if (sc->p) (void)hipFree(sc->p);
-    if (e->rs_pin.p) (void)hipHostFree(e->rs_pin.p);
+    for (auto& sp : e->rs_pin)
+        if (sp.p) (void)hipHostFree(sp.p);
+    if (e->prep_stream) (void)hipStreamDestroy(e->prep_stream);
     for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
     for (void* p : e->allocs) (void)hipFree(p);
     for (auto& L : e->lanes) {
@@ -1683,30 +1720,37 @@ int mocr_recognize_gray_host(mocr_engine* e, const uint8_t* gray, int32_t n, int
 }
 
 // Host pixels uploaded once (an image, or a whole page several crops are cut from) ...
-struct PrepSource { const uint8_t* data; int h, w; int64_t row_stride; int ch; int bgr; };
-// ... and what one crop reads of its source: the rectangle [x, x+w) x [y, y+h)
-struct PrepView { int source, x, y, w, h; };
+struct PrepSource { const uint8_t* data; int h, w; int64_t row_stride; int ch; int bgr; int rot; };
+// ... and what one crop reads of its source: the rectangle [x, x+w) x [y, y+h), then rotated (MOCR_ROTATE_*)
+struct PrepView { int source, x, y, w, h, rot; };
 
 static PrepSource source_of(const mocr_image& im) {
     const int ch = im.channels == MOCR_CHANNELS_BGR ? 3 : im.channels;
     if (!im.data || im.height < 1 || im.width < 1 || im.height > 16384 || im.width > 16384 || (ch != 1 && ch != 3) ||
         im.row_stride < (int64_t)im.width * ch)
         throw ArgError{"bad image descriptor (channels must be 1 = L, 3 = RGB or MOCR_CHANNELS_BGR)", MOCR_ERR_ARG};
-    return PrepSource{im.data, im.height, im.width, im.row_stride, ch, im.channels == MOCR_CHANNELS_BGR ? 1 : 0};
+    if (im.rotate != MOCR_ROTATE_NONE && im.rotate != MOCR_ROTATE_90_CW && im.rotate != MOCR_ROTATE_90_CCW)
+        throw ArgError{"bad image descriptor (rotate must be MOCR_ROTATE_NONE, _90_CW or _90_CCW)", MOCR_ERR_ARG};
+    return PrepSource{im.data, im.height, im.width, im.row_stride, ch, im.channels == MOCR_CHANNELS_BGR ? 1 : 0, im.rotate};
 }
 
 // L conversion + Pillow-exact BILINEAR resize of the views (any sizes) into d_out [views][IMG][IMG] u8 on the
 // device; synchronous (lane 0's stream).  Every source is uploaded once, however many views read it: the crops of
 // a page's detected regions are cut ON THE DEVICE (descriptor = offset + page stride), not copied out on the host.
-static void preprocess_views(mocr_engine* e, const std::vector<PrepSource>& srcs, const PrepView* views, int n, uint8_t* d_out) {
+// prep_enqueue packs the sources into pinned buffer `slot`, and enqueues H2D + the two resize launches on the engine's
+// preparation stream; it does NOT wait for them.  Device scratch (packed sources, horizontal-pass planes, descriptors,
+// coefficient tables) is reused from call to call: everything runs on the ONE preparation stream, in order.  The pinned
+// buffer of a slot may be repacked only once the copy that reads it has finished (the caller's business).
+struct PrepHold { std::vector<ResizeDesc> descs; std::vector<int> coef, bounds; };     // host sources of a pass's small uploads: alive until it has run
+static void prep_enqueue(mocr_engine* e, const std::vector<PrepSource>& srcs, const PrepView* views, int n, uint8_t* d_out, int slot, bool prof,
+                         PrepHold& hold) {
     const int IMG = e->cfg.image_size;
-    if (n > 4096) {          // bounded scratch and grid.y: 4096 crops per pass
-        for (int b = 0; b < n; b += 4096) preprocess_views(e, srcs, views + b, std::min(4096, n - b), d_out + (size_t)b * IMG * IMG);
-        return;
-    }
+    if (n > 4096) throw ArgError{"prep_enqueue: at most 4096 crops per pass", MOCR_ERR_ARG};   // bounded scratch and grid.y
     if (IMG != 224) throw ArgError{"device preprocessing is instantiated for image_size 224", MOCR_ERR_UNSUPPORTED};
-    std::vector<ResizeDesc> descs(n);
-    std::vector<int> coef, bounds;
+    std::vector<ResizeDesc>& descs = hold.descs;
+    std::vector<int>&coef = hold.coef, &bounds = hold.bounds;
+    descs.assign(n, ResizeDesc{});
+    coef.clear(); bounds.clear();
     std::map<int, std::pair<int, int>> placed;        // input size -> (coef offset, bounds offset) in this call's buffers
     std::map<int, long long> src_off;                 // sources this pass reads -> byte offset in the packed upload
     size_t src_bytes = 0, tmp_bytes = 0;
@@ -1736,8 +1780,19 @@ static void preprocess_views(mocr_engine* e, const std::vector<PrepSource>& srcs
             src_bytes += (size_t)sc.h * sc.w * sc.ch;
         }
         ResizeDesc& d = descs[i];
-        d.h = v.h; d.w = v.w; d.channels = sc.ch; d.bgr = sc.bgr; d.stride = sc.w * sc.ch;
-        d.src_off = so->second + ((long long)v.y * sc.w + v.x) * sc.ch;
+        d.channels = sc.ch; d.bgr = sc.bgr;
+        const int stride = sc.w * sc.ch;                        // the packed copy has no row padding
+        const long long origin = so->second + ((long long)v.y * sc.w + v.x) * sc.ch;
+        if (v.rot == MOCR_ROTATE_90_CW) {                       // R[y'][x'] = S[h - 1 - x'][y']   (np.rot90(k = -1))
+            d.h = v.w; d.w = v.h; d.row_step = sc.ch; d.pix_step = -stride;
+            d.src_off = origin + (long long)(v.h - 1) * stride;
+        } else if (v.rot == MOCR_ROTATE_90_CCW) {               // R[y'][x'] = S[x'][w - 1 - y']   (np.rot90(k = 1))
+            d.h = v.w; d.w = v.h; d.row_step = -sc.ch; d.pix_step = stride;
+            d.src_off = origin + (long long)(v.w - 1) * sc.ch;
+        } else {
+            d.h = v.h; d.w = v.w; d.row_step = stride; d.pix_step = sc.ch;
+            d.src_off = origin;
+        }
         d.tmp_off = (long long)tmp_bytes;
         tmp_bytes += (size_t)d.h * IMG;
         place(d.w, d.kx_off, d.bx_off, d.ksx);
@@ -1746,7 +1801,7 @@ static void preprocess_views(mocr_engine* e, const std::vector<PrepSource>& srcs
     }
     // pack the pixel rows of every source (drops the callers' row padding) into the pinned staging buffer, the
     // sources dealt to a few host threads by bytes (2048 crops of 224 x 224 x 3 are 300 MB: ~50 ms on one core)
-    uint8_t* const packed = (uint8_t*)e->grow_pinned(src_bytes);
+    uint8_t* const packed = (uint8_t*)e->grow_pinned(slot, src_bytes);
     {
         std::vector<std::pair<int, long long>> items(src_off.begin(), src_off.end());
         auto pack_range = [&](size_t i0, size_t i1) {
@@ -1777,23 +1832,37 @@ static void preprocess_views(mocr_engine* e, const std::vector<PrepSource>& srcs
     ResizeDesc* d_desc = (ResizeDesc*)e->grow(e->rs_desc, descs.size() * sizeof(ResizeDesc));
     int* d_coef = (int*)e->grow(e->rs_coef, std::max<size_t>(coef.size(), 1) * sizeof(int));
     int* d_bounds = (int*)e->grow(e->rs_bounds, std::max<size_t>(bounds.size(), 1) * sizeof(int));
-    HIPCHECK(hipMemcpyAsync(d_src, packed, src_bytes, hipMemcpyHostToDevice, e->stream));
-    HIPCHECK(hipMemcpyAsync(d_desc, descs.data(), descs.size() * sizeof(ResizeDesc), hipMemcpyHostToDevice, e->stream));
-    if (!coef.empty()) HIPCHECK(hipMemcpyAsync(d_coef, coef.data(), coef.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
-    if (!bounds.empty()) HIPCHECK(hipMemcpyAsync(d_bounds, bounds.data(), bounds.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    hipStream_t st = e->prep_stream;
+    HIPCHECK(hipMemcpyAsync(d_src, packed, src_bytes, hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(d_desc, descs.data(), descs.size() * sizeof(ResizeDesc), hipMemcpyHostToDevice, st));
+    if (!coef.empty()) HIPCHECK(hipMemcpyAsync(d_coef, coef.data(), coef.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    if (!bounds.empty()) HIPCHECK(hipMemcpyAsync(d_bounds, bounds.data(), bounds.size() * sizeof(int), hipMemcpyHostToDevice, st));
     constexpr int ROWS = 8;
-    {
-        ProfScope ps(e, "resize_h", 0, (double)src_bytes + (double)tmp_bytes);
-        hipLaunchKernelGGL((resize_h_kernel<224, ROWS>), dim3((max_h + ROWS - 1) / ROWS, n), dim3(256), 0, e->stream, d_src, d_desc, d_coef,
-                           d_bounds, d_tmp);
-        HIPCHECK(hipGetLastError());
+    hipEvent_t t0 = nullptr, t1 = nullptr, t2 = nullptr;
+    if (prof) { t0 = e->get_event(); t1 = e->get_event(); t2 = e->get_event(); HIPCHECK(hipEventRecord(t0, st)); }
+    hipLaunchKernelGGL((resize_h_kernel<224, ROWS>), dim3((max_h + ROWS - 1) / ROWS, n), dim3(256), 0, st, d_src, d_desc, d_coef, d_bounds, d_tmp);
+    HIPCHECK(hipGetLastError());
+    if (prof) HIPCHECK(hipEventRecord(t1, st));
+    hipLaunchKernelGGL((resize_v_kernel<224, ROWS>), dim3(224 / ROWS, n), dim3(256), 0, st, d_tmp, d_desc, d_coef, d_bounds, d_out);
+    HIPCHECK(hipGetLastError());
+    if (prof) {
+        HIPCHECK(hipEventRecord(t2, st));
+        e->recs.push_back(ProfRec{e->kid("resize_h"), t0, t1, 0, (double)src_bytes + (double)tmp_bytes});
+        hipEvent_t t1b = e->get_event();         // (a record owns both of its events)
+        HIPCHECK(hipEventRecord(t1b, st));
+        e->recs.push_back(ProfRec{e->kid("resize_v"), t1b, t2, 0, (double)tmp_bytes + (double)n * IMG * IMG});
     }
-    {
-        ProfScope ps(e, "resize_v", 0, (double)tmp_bytes + (double)n * IMG * IMG);
-        hipLaunchKernelGGL((resize_v_kernel<224, ROWS>), dim3(224 / ROWS, n), dim3(256), 0, e->stream, d_tmp, d_desc, d_coef, d_bounds, d_out);
-        HIPCHECK(hipGetLastError());
+}
+
+// Synchronous form (test hook mocr_preprocess, small calls): L conversion + Pillow-exact BILINEAR resize of the views
+// into d_out [views][IMG][IMG] u8 on the device.
+static void preprocess_views(mocr_engine* e, const std::vector<PrepSource>& srcs, const PrepView* views, int n, uint8_t* d_out) {
+    const size_t plane = (size_t)e->cfg.image_size * e->cfg.image_size;
+    PrepHold hold;
+    for (int b = 0; b < n; b += 4096) {
+        prep_enqueue(e, srcs, views + b, std::min(4096, n - b), d_out + (size_t)b * plane, 0, e->prof_on, hold);
+        HIPCHECK(hipStreamSynchronize(e->prep_stream));     // the staging buffer and the descriptors are reused by the next pass
     }
-    HIPCHECK(hipStreamSynchronize(e->stream));       // the staging buffer and the descriptors are reused by the next call
 }
 
 static void preprocess_images(mocr_engine* e, const mocr_image* imgs, int n, uint8_t* d_out) {
@@ -1801,23 +1870,94 @@ static void preprocess_images(mocr_engine* e, const mocr_image* imgs, int n, uin
     std::vector<PrepView> views(n);
     for (int i = 0; i < n; ++i) {
         srcs[i] = source_of(imgs[i]);
-        views[i] = PrepView{i, 0, 0, srcs[i].w, srcs[i].h};
+        views[i] = PrepView{i, 0, 0, srcs[i].w, srcs[i].h, srcs[i].rot};
     }
     preprocess_views(e, srcs, views.data(), n, d_out);
 }
 
-// Decode device-resident luminance planes d_gray [n][IMG][IMG] into host outputs, in max_batch-row jobs.
-static void recognize_planes(mocr_engine* e, const uint8_t* d_gray, int n, int32_t* out_ids, int32_t* out_len) {
+// THE host entry points' engine: crops (views of host sources) -> ids.  The views are cut into chunks of max_batch
+// rows = one decode job each.  A producer thread prepares chunk k + 1 (pack into the other pinned buffer, H2D, resize, on
+// the preparation stream) while the lanes decode chunk k; a job's lane stream waits ON THE DEVICE for its chunk's event,
+// so the host never blocks on a preparation.  r02 prepared ALL crops, synchronised, and only then started to decode.
+static void prepare_and_decode(mocr_engine* e, const std::vector<PrepSource>& srcs, const PrepView* views, int n, int32_t* out_ids,
+                               int32_t* out_len) {
     const size_t plane = (size_t)e->cfg.image_size * e->cfg.image_size;
-    for (int base = 0; base < n; base += e->cfg.max_batch) {
+    const int C = std::min(e->cfg.max_batch, 4096), nchunks = (n + C - 1) / C;
+    uint8_t* const d_gray = (uint8_t*)e->grow(e->rs_gray, (size_t)n * plane);
+    auto push_job = [&](int k, hipEvent_t ev) {
         Job j;
-        j.src = d_gray + (size_t)base * plane; j.src_host = false; j.channels = 1;
+        j.wait_ev = ev;
+        j.src = d_gray + (size_t)k * C * plane; j.src_host = false; j.channels = 1;
         j.row_stride = e->cfg.image_size; j.image_stride = (int64_t)plane;
-        j.n = std::min(e->cfg.max_batch, n - base); j.max_len = e->gen_max_len;
-        j.out_ids = out_ids + (size_t)base * e->cfg.max_len; j.out_len = out_len + base; j.out_host = true;
+        j.n = std::min(C, n - k * C); j.max_len = e->gen_max_len;
+        j.out_ids = out_ids + (size_t)k * C * e->cfg.max_len; j.out_len = out_len + (size_t)k * C; j.out_host = true;
         e->pending.push_back(j);
+    };
+    std::vector<PrepHold> holds(nchunks);
+    if (nchunks == 1 || e->prof_on) {              // nothing to overlap (or an instrumented pass: one thread records the events)
+        for (int k = 0; k < nchunks; ++k) {
+            prep_enqueue(e, srcs, views + (size_t)k * C, std::min(C, n - k * C), d_gray + (size_t)k * C * plane, 0, e->prof_on, holds[k]);
+            HIPCHECK(hipStreamSynchronize(e->prep_stream));
+            push_job(k, nullptr);
+        }
+        drive(e);
+        return;
     }
-    drive(e);
+    struct Pipe {
+        std::mutex mu;
+        std::condition_variable cv;
+        int enqueued = 0;                          // chunks whose preparation has been enqueued (event recorded)
+        bool abort = false;
+        std::exception_ptr err;
+    } pipe;
+    std::vector<hipEvent_t> ev(nchunks, nullptr);
+    for (auto& x : ev) HIPCHECK(hipEventCreateWithFlags(&x, hipEventDisableTiming));
+    std::thread producer([&] {
+        try {
+            HIPCHECK(hipSetDevice(e->cfg.device));
+            for (int k = 0; k < nchunks; ++k) {
+                { std::lock_guard<std::mutex> lk(pipe.mu); if (pipe.abort) return; }
+                if (k >= 2) HIPCHECK(hipEventSynchronize(ev[k - 2]));      // the copy out of this pinned buffer has finished
+                prep_enqueue(e, srcs, views + (size_t)k * C, std::min(C, n - k * C), d_gray + (size_t)k * C * plane, k & 1, false, holds[k]);
+                HIPCHECK(hipEventRecord(ev[k], e->prep_stream));
+                { std::lock_guard<std::mutex> lk(pipe.mu); pipe.enqueued = k + 1; }
+                pipe.cv.notify_all();
+            }
+        } catch (...) {
+            std::lock_guard<std::mutex> lk(pipe.mu);
+            pipe.err = std::current_exception();
+            pipe.cv.notify_all();
+        }
+    });
+    auto finish = [&](bool aborting) {
+        { std::lock_guard<std::mutex> lk(pipe.mu); if (aborting) pipe.abort = true; }
+        producer.join();
+        (void)hipStreamSynchronize(e->prep_stream);
+        for (auto x : ev) if (x) (void)hipEventDestroy(x);
+    };
+    try {
+        int next = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(pipe.mu);
+                if (pipe.err) std::rethrow_exception(pipe.err);
+                while (next < pipe.enqueued) { push_job(next, ev[next]); ++next; }
+            }
+            const bool busy = (e->cfg.dtype == MOCR_BF16) ? pump_once<bf16_t>(e) : pump_once<float>(e);
+            if (next == nchunks && !busy) break;
+            if (!busy) {                           // every lane idle, the next chunk not yet enqueued: wait for the producer
+                std::unique_lock<std::mutex> lk(pipe.mu);
+                pipe.cv.wait_for(lk, std::chrono::milliseconds(2), [&] { return pipe.enqueued > next || pipe.err; });
+            }
+        }
+        for (auto& L : e->lanes) HIPCHECK(hipStreamSynchronize(L.ctx.stream));
+    } catch (...) {
+        e->pending.clear();
+        for (auto& L : e->lanes) { L.active = false; L.jobs.clear(); (void)hipStreamSynchronize(L.ctx.stream); }
+        finish(true);
+        throw;
+    }
+    finish(false);
 }
 
 int mocr_preprocess(mocr_engine* e, const mocr_image* images, int32_t n, uint8_t* out_gray) {
@@ -1842,12 +1982,13 @@ int mocr_recognize_images(mocr_engine* e, const mocr_image* images, int32_t n, i
         if (!images || !out_ids || !out_len) throw ArgError{"null pointer", MOCR_ERR_ARG};
         HIPCHECK(hipSetDevice(e->cfg.device));
         drive(e);
-        const size_t plane = (size_t)e->cfg.image_size * e->cfg.image_size;
-        e->bind(0);
-        uint8_t* d_gray = (uint8_t*)e->grow(e->rs_gray, (size_t)n * plane);
-        preprocess_images(e, images, n, d_gray);
-        e->unbind(0);
-        recognize_planes(e, d_gray, n, out_ids, out_len);
+        std::vector<PrepSource> srcs(n);
+        std::vector<PrepView> views(n);
+        for (int i = 0; i < n; ++i) {
+            srcs[i] = source_of(images[i]);
+            views[i] = PrepView{i, 0, 0, srcs[i].w, srcs[i].h, srcs[i].rot};
+        }
+        prepare_and_decode(e, srcs, views.data(), n, out_ids, out_len);
     });
 }
 
@@ -1881,21 +2022,14 @@ int mocr_recognize_regions(mocr_engine* e, const mocr_image* pages, int32_t n_pa
         for (int i = 0; i < n_regions; ++i) {
             const mocr_region& r = regions[i];
             if (r.page < 0 || r.page >= n_pages) throw ArgError{"region of an unknown page", MOCR_ERR_ARG};
-            PrepView v{r.page, 0, 0, 0, 0};
+            PrepView v{r.page, 0, 0, 0, 0, MOCR_ROTATE_NONE};
             if (!padded_region(r, srcs[r.page].h, srcs[r.page].w, v)) continue;
             where[i] = (int)views.size();
             views.push_back(v);
         }
         const int L = e->cfg.max_len, nv = (int)views.size();
         std::vector<int32_t> ids((size_t)nv * L), lens(nv);
-        if (nv > 0) {
-            const size_t plane = (size_t)e->cfg.image_size * e->cfg.image_size;
-            e->bind(0);
-            uint8_t* d_gray = (uint8_t*)e->grow(e->rs_gray, (size_t)nv * plane);
-            preprocess_views(e, srcs, views.data(), nv, d_gray);
-            e->unbind(0);
-            recognize_planes(e, d_gray, nv, ids.data(), lens.data());
-        }
+        if (nv > 0) prepare_and_decode(e, srcs, views.data(), nv, ids.data(), lens.data());
         for (int i = 0; i < n_regions; ++i) {
             int32_t* row = out_ids + (size_t)i * L;
             if (where[i] < 0) {

@@ -24,18 +24,6 @@
 #pragma once
 #include "kernels_gemm.h"
 
-// x * Phi(x) with Phi(x) ~ 1 / (1 + exp(-x (a + b x^2 + c x^4))): |error| <= 2.6e-5 against the erf form over the whole
-// line (fitted minimax, tools/fit_gelu.py) - 1/150 of a bf16 half-ulp at |y| ~ 1 - in 9 VALU instructions, two of them
-// transcendental, instead of gelu_fast's 16.  x^2 is clamped at 64 (the odd polynomial turns over at |x| ~ 10; at
-// |x| = 8 the sigmoid already is 0 or 1 in fp32).  Constants carry the -log2(e) of exp2.
-__device__ __forceinline__ float gelu_sig(float x) {
-    const float x2 = fminf(x * x, 64.0f);
-    float t = fmaf(x2, 1.0142628e-3f, -1.0677572e-1f);      // -log2e * (c x^2 + b)
-    t = fmaf(x2, t, -2.3011213f);                            // -log2e * a
-    const float e = __builtin_amdgcn_exp2f(x * t);
-    return x * __builtin_amdgcn_rcpf(1.0f + e);
-}
-
 constexpr int PERS_LDS = 160 * 1024;      // four 32 KiB ring slots + 32 KiB that only the epilogue uses
 
 // SPLIT_DMA: the LDS-DMA of a K-tile is requested by waves 0-3 alone (8 pieces each; those waves then never have a
@@ -48,6 +36,11 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
     static_assert(EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID, "epilogues of the encoder layers");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
+#ifdef MOCR_EXPERIMENTS
+    const int ablate = p.ablate, stagger = p.stagger;      // diagnostics (MOCR_GEMM_ABLATE / MOCR_GEMM_STAGGER): experiments build only
+#else
+    constexpr int ablate = 0, stagger = 0;
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
@@ -69,8 +62,8 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
     if (tile >= tile_end) return;
     // Experiment knob (MOCR_GEMM_STAGGER, x 1024 cycles): the four CUs that are neighbours in an XCD's block order start a
     // quarter, a half, three quarters of that time apart, so that the chip's blocks do not all reach their epilogues at once
-    if (p.stagger > 0) {
-        const int units = (int)((blockIdx.x >> 3) & 3) * p.stagger / 4;
+    if (stagger > 0) {
+        const int units = (int)((blockIdx.x >> 3) & 3) * stagger / 4;
         for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(16);
     }
     const int nt = p.k_per_split / 32;            // even, >= 4 (checked on the host)
@@ -92,7 +85,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
     auto pf_set = [&]() {
         int tm, tn;
         gemm_tile_of(p, pf_tile, tm, tn);
-        if (p.ablate & 16) { tm &= 3; tn = 0; }              // diagnostics: every tile reads the same few (L2-resident) operand panels
+        if (ablate & 16) { tm &= 3; tn = 0; }              // diagnostics: every tile reads the same few (L2-resident) operand panels
         pf_a = (const char*)p.A + (size_t)(tm * BM) * a_row + a_lane;
         pf_w = (const char*)p.W + (size_t)(tn * BN) * w_row + w_lane;
     };
@@ -100,7 +93,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
     auto stage_next = [&]() {                    // no-op once the block's last K-tile has been requested
         if (pf_tile >= tile_end) return;
         if (!issues_dma) { ++pf_g; if (++pf_kt == nt) { pf_kt = 0; pf_tile += tstride; } return; }
-        if ((p.ablate & 2) && pf_g >= 3) { ++pf_g; if (++pf_kt == nt) { pf_kt = 0; pf_tile += tstride; } return; }      // diagnostics: K loop without DMA
+        if ((ablate & 2) && pf_g >= 3) { ++pf_g; if (++pf_kt == nt) { pf_kt = 0; pf_tile += tstride; } return; }      // diagnostics: K loop without DMA
         char* sa = smem + (pf_g & 3) * STAGE + wave * 1024;
         const char* ga = pf_a + (size_t)pf_kt * 64;
         const char* gw = pf_w + (size_t)pf_kt * 64;
@@ -211,7 +204,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
         // LDS free right now: the slot of the K-tile just multiplied, (g - 1) & 3 (every wave passed that K-tile's barrier
         // with all its fragments in registers), and the spare 32 KiB.  K-tiles g, g + 1, g + 2 of the NEXT tile sit in the
         // other three slots (landed / in flight); P holds the first six fragments of K-tile g already.
-        if (p.ablate & 4) {                      // diagnostics: no epilogue
+        if (ablate & 4) {                      // diagnostics: no epilogue
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -241,7 +234,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             v[r] = acc[j][i][r] + bias[j][r];
-                            if constexpr (EPI == EPI_BIAS_GELU) { if (!(p.ablate & 32)) v[r] = gelu_sig(v[r]); }
+                            if constexpr (EPI == EPI_BIAS_GELU) { if (!(ablate & 32)) v[r] = gelu_fast(v[r]); }
                             acc[j][i][r] = 0.f;
                         }
                         uint2 u;
@@ -279,7 +272,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
                             const int sr = 32 * sw + 16 * hf + 2 * it + rsel;
                             const int row = (sr >> 6) * 128 + 64 * h + (sr & 63);
                             // non-temporal: the QKV / FC1 output passes through once (r02: +4 % on the encoder)
-                            if ((!guard || m0 + row < p.M) && !(p.ablate & 8)) st16_nt(obase + (size_t)row * ldo, v[it]);
+                            if ((!guard || m0 + row < p.M) && !(ablate & 8)) st16_nt(obase + (size_t)row * ldo, v[it]);
                         }
                     }
                 } else {
@@ -333,7 +326,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
                         for (int it = 0; it < 8; ++it) {
                             const int sr = 16 * sw + 8 * hf + it;
                             const int row = (sr >> 5) * 128 + 32 * q + (sr & 31);
-                            if ((!guard || m0 + row < p.M) && !(p.ablate & 8))
+                            if ((!guard || m0 + row < p.M) && !(ablate & 8))
                                 *reinterpret_cast<float4*>(obase + (size_t)row * ldo) =
                                     make_float4(v[it].x + bias_row.x, v[it].y + bias_row.y, v[it].z + bias_row.z, v[it].w + bias_row.w);
                         }

@@ -70,11 +70,15 @@ static ResampleTable make_resample_table(int in_size, int out_size) {
     return t;
 }
 
-// One image of a preprocessing batch (device-side descriptor).
+// One image of a preprocessing batch (device-side descriptor).  The image the resize SEES has h rows of w pixels; pixel
+// (y, x) of it sits at src_off + y * row_step + x * pix_step in the packed source buffer.  An unrotated crop has
+// (row_step, pix_step) = (bytes per source row, bytes per pixel); the reference's orientation-only rotation
+// (src/core/workers.py:320-326, src/ui/main_window.py:9787-9795: cv2.ROTATE_90_CLOCKWISE / _COUNTERCLOCKWISE before the
+// recogniser) is the same crop read with swapped, signed steps - no copy on the host, no extra pass on the device.
 struct ResizeDesc {
-    long long src_off;     // byte offset of the image in the packed source buffer
+    long long src_off;     // byte offset of pixel (0, 0) of the (rotated) image in the packed source buffer
     long long tmp_off;     // byte offset of its [h][OUT] horizontal-pass plane
-    int h, w, stride, channels;
+    int h, w, row_step, pix_step, channels;
     int bgr;               // 3-channel pixels are stored B,G,R (OpenCV order, what the reference's crop tools hold)
     int kx_off, bx_off, ksx;   // int offsets into the coefficient / bounds buffers, taps per output (0: pass skipped)
     int ky_off, by_off, ksy;
@@ -111,13 +115,13 @@ __global__ __launch_bounds__(256) void resize_h_kernel(const uint8_t* __restrict
         k = coef + d.kx_off + xx * d.ksx;
     }
     for (int y = y0; y < min(y0 + ROWS, d.h); ++y) {
-        const uint8_t* row = src + d.src_off + (size_t)y * d.stride;
+        const uint8_t* row = src + d.src_off + (long long)y * d.row_step;
         uint8_t o;
         if (!d.ksx) {                        // width already OUT: Pillow skips the pass
-            o = (uint8_t)rs_luma(row + (size_t)xx * d.channels, d.channels, d.bgr);
+            o = (uint8_t)rs_luma(row + (long long)xx * d.pix_step, d.channels, d.bgr);
         } else {
             int acc = 1 << (MOCR_RS_PRECISION_BITS - 1);
-            for (int x = 0; x < cnt; ++x) acc += rs_luma(row + (size_t)(xmin + x) * d.channels, d.channels, d.bgr) * k[x];
+            for (int x = 0; x < cnt; ++x) acc += rs_luma(row + (long long)(xmin + x) * d.pix_step, d.channels, d.bgr) * k[x];
             o = rs_clip8(acc);
         }
         tmp[d.tmp_off + (size_t)y * OUT + xx] = o;

@@ -34,7 +34,7 @@ _P = C.c_void_p
 class MocrImage(C.Structure):
     """include/mocr.h: mocr_image"""
     _fields_ = [("data", C.c_void_p), ("height", C.c_int32), ("width", C.c_int32), ("row_stride", C.c_int64),
-                ("channels", C.c_int32)]
+                ("channels", C.c_int32), ("rotate", C.c_int32)]
 
 
 class MocrRegion(C.Structure):
@@ -43,6 +43,7 @@ class MocrRegion(C.Structure):
 
 
 CHANNELS_BGR = -3
+ROTATE_NONE, ROTATE_90_CW, ROTATE_90_CCW = 0, 1, 2
 
 SYMBOLS = {
     "mocr_abi_version": (C.c_int, []),
@@ -97,7 +98,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         fn = getattr(lib, name)     # AttributeError if the .so does not export it
         fn.restype = res
         fn.argtypes = args
-    if lib.mocr_abi_version() != 1:
+    if lib.mocr_abi_version() != 2:
         raise MocrError("libmocr_hip.so ABI version mismatch")
     if path is None:
         _lib = lib

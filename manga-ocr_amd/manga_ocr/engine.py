@@ -106,10 +106,11 @@ class Engine:
         self._check(self.lib.mocr_recognize(self._h, _ptr(a), n, h, w, w * ch, h * w * ch, ch, _ptr(ids), _ptr(lens)))
         return ids, lens
 
-    def _image_descs(self, images, bgr: bool = False):
+    def _image_descs(self, images, bgr: bool = False, rotate=None):
         """numpy uint8 [h,w] (L) or [h,w,3] (RGB; B,G,R order when `bgr`) arrays of any sizes -> (ctypes array of
         mocr_image, keep-alive list).  Arrays with contiguous pixels and any row stride are passed as they are
-        (a crop that is a view into a page is not copied here)."""
+        (a crop that is a view into a page is not copied here).  ``rotate``: per image 0 / ROTATE_90_CW / ROTATE_90_CCW -
+        the reference's orientation-only rotation, done by the device's resize addressing."""
         keep = []
         descs = (_capi.MocrImage * len(images))()
         for i, im in enumerate(images):
@@ -129,15 +130,17 @@ class Engine:
             d.height, d.width = a.shape[0], a.shape[1]
             d.row_stride = a.strides[0]
             d.channels = _capi.CHANNELS_BGR if (bgr and ch == 3) else ch
+            d.rotate = int(rotate[i]) if rotate is not None else 0
         return descs, keep
 
-    def recognize_images(self, images, bgr: bool = False) -> Tuple[np.ndarray, np.ndarray]:
-        """Crops of any sizes (list of uint8 [h,w] / [h,w,3] arrays; `bgr`: 3-channel crops are in OpenCV order):
-        luminance conversion and the Pillow-exact BILINEAR resize to 224x224 run on the device.
+    def recognize_images(self, images, bgr: bool = False, rotate=None) -> Tuple[np.ndarray, np.ndarray]:
+        """Crops of any sizes (list of uint8 [h,w] / [h,w,3] arrays; `bgr`: 3-channel crops are in OpenCV order;
+        `rotate`: per crop 0 / 1 (90 degrees clockwise) / 2 (counter-clockwise), applied on the device): luminance
+        conversion and the Pillow-exact BILINEAR resize to 224x224 run on the device.
         Returns (ids int32 [n,max_len], lengths int32 [n])."""
         if len(images) == 0:
             return np.zeros((0, self.spec.max_len), dtype=np.int32), np.zeros(0, dtype=np.int32)
-        descs, keep = self._image_descs(images, bgr)
+        descs, keep = self._image_descs(images, bgr, rotate)
         n = len(keep)
         ids = np.zeros((n, self.spec.max_len), dtype=np.int32)
         lens = np.zeros(n, dtype=np.int32)
@@ -165,9 +168,9 @@ class Engine:
     def graph_count(self) -> int:
         return int(self.lib.mocr_graph_count(self._h))
 
-    def preprocess(self, images, bgr: bool = False) -> np.ndarray:
+    def preprocess(self, images, bgr: bool = False, rotate=None) -> np.ndarray:
         """Test hook: the uint8 [n,224,224] planes the encoder sees for these crops."""
-        descs, keep = self._image_descs(images, bgr)
+        descs, keep = self._image_descs(images, bgr, rotate)
         out = np.zeros((len(keep), self.spec.image_size, self.spec.image_size), dtype=np.uint8)
         self._check(self.lib.mocr_preprocess(self._h, descs, len(keep), _ptr(out)))
         return out

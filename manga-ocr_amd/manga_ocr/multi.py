@@ -93,7 +93,10 @@ def _views(buf: np.ndarray, descs) -> List[np.ndarray]:
 # ------------------------------------------------------------------------------------------------ child
 def _decode_chunk(engine, job, buf, lo, hi):
     if job["kind"] == "images":
-        return engine.recognize_images(_views(buf, job["descs"][lo:hi]), job["bgr"])
+        rot = job.get("rotate")
+        if rot is None:                          # (engines and stand-ins that do not know the argument are not handed it)
+            return engine.recognize_images(_views(buf, job["descs"][lo:hi]), job["bgr"])
+        return engine.recognize_images(_views(buf, job["descs"][lo:hi]), job["bgr"], rot[lo:hi])
     # regions: this chunk's rectangles, and only the pages they touch
     mine = job["regs"][lo:hi]
     used = sorted({r[0] for r in mine})
@@ -479,12 +482,13 @@ class MultiGpuEngine:
         return descs, off, fill
 
     # ------------------------------------------------------------------ the hot path
-    def recognize_images(self, images, bgr: bool = False) -> Tuple[np.ndarray, np.ndarray]:
+    def recognize_images(self, images, bgr: bool = False, rotate=None) -> Tuple[np.ndarray, np.ndarray]:
         n = len(images)
         if n == 0:
             return np.zeros((0, self.max_len), np.int32), np.zeros(0, np.int32)
         descs, size, fill = self._pack(images)
-        return self._run(n, size, fill, dict(kind="images", descs=descs, bgr=bool(bgr)))
+        return self._run(n, size, fill, dict(kind="images", descs=descs, bgr=bool(bgr),
+                                             rotate=[int(r) for r in rotate] if rotate is not None else None))
 
     def recognize_regions(self, pages, regions, bgr: bool = True) -> Tuple[np.ndarray, np.ndarray]:
         regs = [tuple(int(v) for v in r) for r in regions]

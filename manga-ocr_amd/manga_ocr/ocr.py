@@ -200,9 +200,10 @@ class MangaOcr:
         return ids_to_text(self.vocab, ids)
 
     # ------------------------------------------------------------------ batch surface (callers that hold many crops)
-    def recognize_ids(self, crops: Sequence[np.ndarray], bgr: bool = False) -> List[np.ndarray]:
-        """uint8 crops of any sizes ([h,w] luminance or [h,w,3] RGB; BGR with ``bgr=True``) -> token ids (without padding)."""
-        ids, lens = self.engine.recognize_images(list(crops), bgr)
+    def recognize_ids(self, crops: Sequence[np.ndarray], bgr: bool = False, rotate: Optional[Sequence[int]] = None) -> List[np.ndarray]:
+        """uint8 crops of any sizes ([h,w] luminance or [h,w,3] RGB; BGR with ``bgr=True``; ``rotate``: per crop 0 / 1 (90
+        degrees clockwise) / 2 (counter-clockwise), done by the device) -> token ids (without padding)."""
+        ids, lens = self.engine.recognize_images(list(crops), bgr, rotate)
         return [ids[i, :lens[i]].copy() for i in range(len(lens))]
 
     def recognize_batch(self, images: Sequence) -> List[str]:
@@ -215,10 +216,17 @@ class MangaOcr:
         crops (the crop-job queue) uses instead of wrapping each one in a PIL image."""
         return [ids_to_text(self.vocab, r) for r in self.recognize_ids(list(crops))]
 
-    def recognize_bgr(self, crops_bgr: Sequence[np.ndarray]) -> List[str]:
+    def recognize_bgr(self, crops_bgr: Sequence[np.ndarray], orientations: Optional[Sequence[str]] = None) -> List[str]:
         """BGR crops exactly as the crop tools and the worker hold them (``cropped_cv_img``, ``src/core/workers.py:300``):
-        the BGR -> RGB swap of ``src/ui/main_window.py:9800`` is folded into the device's luminance conversion."""
-        return [ids_to_text(self.vocab, r) for r in self.recognize_ids(list(crops_bgr), bgr=True)]
+        the BGR -> RGB swap of ``src/ui/main_window.py:9800`` is folded into the device's luminance conversion, and with
+        ``orientations`` (the jobs' "Auto-Detect" / "Vertical" / "Horizontal" settings) the orientation-only rotation of
+        ``src/core/workers.py:320-326`` / ``src/ui/main_window.py:9787-9795`` into the device's resize addressing."""
+        from .queue_worker import rotation_code
+        crops = list(crops_bgr)
+        rot = None
+        if orientations is not None:
+            rot = [rotation_code(c.shape[0], c.shape[1], o) for c, o in zip(crops, orientations)]
+        return [ids_to_text(self.vocab, r) for r in self.recognize_ids(crops, bgr=True, rotate=rot)]
 
     def recognize_regions(self, pages_bgr: Sequence[np.ndarray], regions) -> List[str]:
         """``regions``: (page_index, x, y, w, h) bounding rectangles on BGR pages; every page is uploaded once and

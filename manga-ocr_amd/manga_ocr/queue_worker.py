@@ -37,6 +37,19 @@ def orient_crop(bgr: np.ndarray, orientation: str = "Auto-Detect") -> np.ndarray
     return bgr
 
 
+ROTATE_NONE, ROTATE_90_CW, ROTATE_90_CCW = 0, 1, 2        # include/mocr.h: MOCR_ROTATE_*
+
+
+def rotation_code(h: int, w: int, orientation: str = "Auto-Detect") -> int:
+    """The same rule as :func:`orient_crop`, as the code the engine's resize takes (``mocr_image.rotate``): the rotation
+    then happens in the device's source addressing and the crop is handed over as it lies in memory."""
+    if orientation == "Vertical" and w > h:
+        return ROTATE_90_CW
+    if orientation == "Horizontal" and h > w:
+        return ROTATE_90_CCW
+    return ROTATE_NONE
+
+
 def bgr_to_rgb(bgr: np.ndarray) -> np.ndarray:
     return np.ascontiguousarray(bgr[..., ::-1])
 
@@ -78,9 +91,17 @@ class CropJobQueue:
     or a function over ``Engine.recognize_images`` + tokenizer decode.  ``on_complete(job, raw_text)`` and ``on_error(job, exc)``
     are called from the worker thread, in submission order."""
 
-    def __init__(self, recognize: Callable[[List[np.ndarray]], Sequence[str]], on_complete: Callable[[CropJob, str], None],
-                 on_error: Optional[Callable[[CropJob, BaseException], None]] = None, max_batch: int = 64):
+    def __init__(self, recognize: Optional[Callable[[List[np.ndarray]], Sequence[str]]], on_complete: Callable[[CropJob, str], None],
+                 on_error: Optional[Callable[[CropJob, BaseException], None]] = None, max_batch: int = 64,
+                 recognize_oriented: Optional[Callable[[List[np.ndarray], List[str]], Sequence[str]]] = None):
+        """``recognize_oriented(bgr_crops, orientations) -> texts`` (e.g. ``MangaOcr.recognize_bgr``) takes the jobs' crops
+        exactly as the crop tools produced them - BGR, unrotated - together with their orientation settings: rotation
+        and channel order are then the engine's business (device side).  Without it the worker rotates and swaps the
+        channels on the host (the reference's own order of operations) and calls ``recognize(rgb_crops)``."""
+        if recognize is None and recognize_oriented is None:
+            raise ValueError("give recognize or recognize_oriented")
         self._recognize, self._done, self._err = recognize, on_complete, on_error or (lambda job, exc: None)
+        self._oriented = recognize_oriented
         self.max_batch = max_batch
         self._jobs: List[CropJob] = []
         self._cv = threading.Condition()
@@ -138,10 +159,14 @@ class CropJobQueue:
             todo = [j for j in batch if not j.pre_detected_text]
             texts: dict = {}
             errors: dict = {}
+            def run(jobs):
+                if self._oriented is not None:
+                    return list(self._oriented([j.crop_bgr for j in jobs], [j.orientation for j in jobs]))
+                return list(self._recognize([bgr_to_rgb(orient_crop(j.crop_bgr, j.orientation)) for j in jobs]))
+
             if todo:
                 try:
-                    crops = [bgr_to_rgb(orient_crop(j.crop_bgr, j.orientation)) for j in todo]
-                    out = list(self._recognize(crops))
+                    out = run(todo)
                     if len(out) != len(todo):
                         raise RuntimeError("recogniser returned a different number of texts than crops")
                     texts = {j.seq: t for j, t in zip(todo, out)}
@@ -149,7 +174,7 @@ class CropJobQueue:
                     # one bad crop must not cost its neighbours their result: redo the batch crop by crop
                     for j in todo:
                         try:
-                            texts[j.seq] = list(self._recognize([bgr_to_rgb(orient_crop(j.crop_bgr, j.orientation))]))[0]
+                            texts[j.seq] = run([j])[0]
                         except BaseException as exc:      # noqa: BLE001 - reported per job, the loop lives on
                             errors[j.seq] = exc
             for j in batch:

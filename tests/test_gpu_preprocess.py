@@ -57,6 +57,38 @@ def test_device_preprocess_extremes_and_strides():
         eng.preprocess([np.zeros((4, 4, 2), np.uint8)])
 
 
+@pytest.mark.parametrize("bgr", [False, True])
+def test_device_rotation_is_bit_exact_with_rot90_then_pillow(bgr):
+    """the reference's orientation-only rotation (src/core/workers.py:320-326,
+    src/ui/main_window.py:9787-9795: cv2.ROTATE_90_CLOCKWISE for "Vertical" + landscape, _COUNTERCLOCKWISE for
+    "Horizontal" + portrait) folded into the resize kernel's source addressing: mocr_image.rotate on the crop as it lies
+    in memory == np.rot90 on the host followed by the oracle's Pillow restatement, plane for plane, for every case of the
+    rule, RGB / BGR / L, odd sizes, a 224-sized side (skipped pass) and a crop that is a strided view into a page."""
+    from manga_ocr.queue_worker import ROTATE_90_CCW, ROTATE_90_CW, ROTATE_NONE, orient_crop, rotation_code
+    eng = engine("bf16")
+    rs = np.random.RandomState(21 + bgr)
+    page = rs.randint(0, 256, size=(700, 900, 3), dtype=np.uint8)
+    crops = [rs.randint(0, 256, size=(h, w, 3), dtype=np.uint8) for (h, w) in ((90, 300), (300, 90), (224, 51), (51, 224), (1, 7), (333, 224))]
+    crops += [page[100:260, 40:500], page[5:600, 700:820]]                 # views with the page's row stride
+    crops += [rs.randint(0, 256, size=(64, 200), dtype=np.uint8)]          # L
+    for orient in ("Vertical", "Horizontal", "Auto-Detect"):
+        rot = [rotation_code(c.shape[0], c.shape[1], orient) for c in crops]
+        got = eng.preprocess(crops, bgr=bgr, rotate=rot)
+        for c, r, plane in zip(crops, rot, got):
+            host = orient_crop(c, orient)                                  # the reference's own order: rotate first ...
+            assert (r == ROTATE_NONE) == (host is c)
+            if host.ndim == 3:
+                rgb = np.ascontiguousarray(host[..., ::-1]) if bgr else np.ascontiguousarray(host)
+                want = pil_ops.preprocess_rgb_to_gray224(rgb)              # ... then BGR -> RGB, convert('L'), resize
+            else:
+                want = pil_ops.resize_bilinear_u8(np.ascontiguousarray(host), 224, 224)
+            np.testing.assert_array_equal(plane, want, err_msg=f"{c.shape} {orient} rot={r}")
+        assert ROTATE_90_CW in rot or ROTATE_90_CCW in rot or orient == "Auto-Detect"
+    with pytest.raises(Exception):
+        eng.preprocess(crops[:1], rotate=[3])
+    report(f"device rotation (mocr_image.rotate) == np.rot90 + Pillow restatement, {len(crops)} crops x 3 orientation settings, bgr={bgr}")
+
+
 def test_recognize_images_equals_host_resize_path():
     """Crops of mixed sizes through mocr_recognize_images == the same crops resized by the oracle's Pillow
     restatement on the host and sent through mocr_recognize: the planes are bit-identical, so are the ids."""

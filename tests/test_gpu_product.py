@@ -60,6 +60,18 @@ def test_crop_job_queue_drives_bgr_jobs_through_the_engine_and_matches_the_oracl
     # the BGR entry point folds the channel swap into the device's luminance conversion: same texts
     direct = m.recognize_bgr([orient_crop(j.crop_bgr, j.orientation) for j in jobs if not j.pre_detected_text])
     assert direct == [t for (p, t) in done if p != "pre"]
+    # ... and with the orientations handed over too, the rotation into the device's resize addressing: the queue then passes
+    # the crops exactly as the crop tools made them (no host rotate, no host channel swap)
+    done2 = []
+    q2 = CropJobQueue(None, lambda job, text: done2.append((job.payload, text)), lambda job, exc: errs.append((job.payload, exc)),
+                      max_batch=4, recognize_oriented=m.recognize_bgr)
+    try:
+        for j in jobs:
+            q2.submit(j)
+        assert q2.join(timeout=300)
+    finally:
+        q2.close()
+    assert not errs and done2 == done
     report(f"CropJobQueue -> MangaOcr(fp32) == oracle texts for {len(jobs) - 1} BGR jobs of mixed size/orientation")
     m.close()
 
@@ -175,14 +187,15 @@ def test_graph_cache_is_bounded_and_padding_rows_do_not_leak():
 
 def test_default_sized_drop_in_reaches_the_device_resident_rate():
     """MangaOcr at DEFAULT settings (two lanes, internal batch sized from the free HBM) must reach
-    the regime the bench measures: >= 2048 crops through recognize_batch (host arrays in, strings out) within 2x of the
-    same engine's device-resident rate."""
+    the regime the bench measures: 4096 crops through recognize_batch (host arrays in, strings out) within 1.15x of the
+    same engine's device-resident time (r02: 2x; r03: the host entry points prepare chunk k + 1 - pack, H2D, resize -
+    while chunk k decodes)."""
     from manga_ocr import MangaOcr
     drop_engines()
     m = MangaOcr(synthetic_seed=0)
     try:
         assert m.max_batch >= 1024, m.max_batch
-        n = 2048
+        n = 2 * m.max_batch
         gray = crops(99, n)
         imgs = list(gray)
         m.recognize_batch_arrays(imgs[:n])                       # warm: graph captures for this row count
@@ -204,7 +217,7 @@ def test_default_sized_drop_in_reaches_the_device_resident_rate():
             best = min(best, time.perf_counter() - t1)
         report(f"MangaOcr() defaults (max_batch {m.max_batch}, 2 lanes): {n} crops host->strings {n / dt:.0f} crops/s; "
                f"device-resident {n / best:.0f} crops/s; ratio {best / dt:.2f}")
-        assert dt <= 2.0 * best + 0.05
+        assert dt <= 1.15 * best + 0.03
     finally:
         m.close()
 

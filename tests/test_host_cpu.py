@@ -27,7 +27,7 @@ def test_library_exports_every_symbol_of_the_header(lib):
     assert declared == set(_capi.SYMBOLS), declared ^ set(_capi.SYMBOLS)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.mocr_abi_version() == 1
+    assert lib.mocr_abi_version() == 2
 
 
 def test_config_struct_matches_header():

@@ -5,8 +5,8 @@ import threading
 import numpy as np
 import pytest
 
-from manga_ocr.queue_worker import (CropJob, CropJobQueue, bgr_to_rgb, clean_and_join, ocr_failed, orient_crop,
-                                    padded_region_crop)
+from manga_ocr.queue_worker import (ROTATE_90_CCW, ROTATE_90_CW, ROTATE_NONE, CropJob, CropJobQueue, bgr_to_rgb, clean_and_join,
+                                    ocr_failed, orient_crop, padded_region_crop, rotation_code)
 
 
 def test_orientation_rule():
@@ -21,6 +21,40 @@ def test_orientation_rule():
     assert ccw.shape == (2, 5, 3)
     np.testing.assert_array_equal(ccw[0, 0], port[0, 1])                # top-right -> top-left
     np.testing.assert_array_equal(bgr_to_rgb(land)[..., 0], land[..., 2])
+
+
+def test_rotation_code_is_the_orientation_rule():
+    """The code handed to the engine (mocr_image.rotate) follows src/core/workers.py:320-326 case for case: what
+    orient_crop does to the pixels on the host, the device does for these codes."""
+    for (h, w) in ((2, 5), (5, 2), (4, 4)):
+        a = np.arange(h * w * 3, dtype=np.uint8).reshape(h, w, 3)
+        for o in ("Auto-Detect", "Vertical", "Horizontal", "whatever"):
+            code = rotation_code(h, w, o)
+            want = {ROTATE_NONE: a, ROTATE_90_CW: np.rot90(a, k=-1), ROTATE_90_CCW: np.rot90(a, k=1)}[code]
+            np.testing.assert_array_equal(orient_crop(a, o), want)
+    assert rotation_code(2, 5, "Vertical") == ROTATE_90_CW and rotation_code(5, 2, "Horizontal") == ROTATE_90_CCW
+    assert rotation_code(5, 2, "Vertical") == ROTATE_NONE and rotation_code(2, 5, "Horizontal") == ROTATE_NONE
+
+
+def test_oriented_recogniser_gets_the_raw_bgr_crops_and_their_orientations():
+    seen, done = [], []
+
+    def recognize_oriented(crops, orients):
+        seen.append((list(crops), list(orients)))
+        return [f"{c.shape[0]}x{c.shape[1]}:{o}" for c, o in zip(crops, orients)]
+
+    q = CropJobQueue(None, lambda j, t: done.append((j.payload, t)), max_batch=4, recognize_oriented=recognize_oriented)
+    jobs = [CropJob(_crop(i, 4, 9), orientation=o, payload=i) for i, o in enumerate(("Vertical", "Horizontal", "Auto-Detect"))]
+    try:
+        for j in jobs:
+            q.submit(j)
+        assert q.join(20)
+    finally:
+        q.close()
+    assert done == [(0, "4x9:Vertical"), (1, "4x9:Horizontal"), (2, "4x9:Auto-Detect")]
+    assert all(c is j.crop_bgr for (cs, _), _ in zip(seen, [0]) for c, j in zip(cs, jobs))     # handed over untouched: no rotate, no swap
+    with pytest.raises(ValueError):
+        CropJobQueue(None, lambda j, t: None)
 
 
 def test_padded_region_crop():

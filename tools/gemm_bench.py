@@ -7,6 +7,10 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "manga-ocr_amd")]
+# the A/B tile codes (256 .. 2048, 4098) and the MOCR_* knobs live in the experiments build (build.py --experiments)
+_LAB = os.path.join(ROOT, "manga-ocr_amd", "manga_ocr", "_lib", "libmocr_hip_lab.so")
+if "MOCR_LIB" not in os.environ and os.path.exists(_LAB):
+    os.environ["MOCR_LIB"] = _LAB
 import numpy as np  # noqa: E402,F401
 import torch  # noqa: E402
 

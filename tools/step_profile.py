@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """One isolated batch of B crops through the engine (nothing to merge with): wall time, and the per-kernel
-breakdown from HIP events (an instrumented eager pass).  Run under `rocprofv3 --kernel-trace --stats` for
-the true kernel durations of the graph-replayed pass.
+breakdown from HIP events (an instrumented eager pass).  For the true kernel durations of the graph-replayed pass run it
+under the profiler WITH THE INTERPRETER NAMED after `--` (the profiler's preloaded library initialises the GPU before the
+program starts, so a `#!/usr/bin/env` hop - launching this file directly - would be an exec from a GPU-initialised process):
 
     python tools/step_profile.py --batch 256 [--max-len 300] [--flags N] [--reps 3] [--events]
+    rocprofv3 --kernel-trace --stats -d gpurun_out/prof -- python tools/step_profile.py --batch 256
 """
 import argparse
 import dataclasses
