@@ -41,6 +41,7 @@
 #include "kernels_latent8.h"
 #include "kernels_smallm.h"
 #include "preprocess.h"
+#include "prep_pipeline.h"
 #include "kernels_qqt.h"
 #include "kernels_misc.h"
 
@@ -1213,8 +1214,10 @@ bool pump_once(mocr_engine* e) {
             // An idle lane takes as many queued requests as fit in max_batch rows.  When SEVERAL lanes are idle and the
             // queue would fit into fewer of them, it is split evenly over the idle lanes as long as every part keeps
             // >= SPLIT_MIN rows: two fat batches in flight overlap each other's latency-bound phases (+6 % at 2 x 2560
-            // against 1 x 5120 rows, r02), while below ~1000 rows merging beats overlapping.
-            static const long long SPLIT_MIN = env_int("MOCR_SPLIT_MIN", 1024);
+            // against 1 x 5120 rows, r02), while below that merging beats overlapping.
+            // (r03: 600 instead of 1024 - the 1250 rows a rank of the 8-GPU queue run gets decode as 2 x 625 in 258 ms
+            // instead of 270 ms as one batch)
+            static const long long SPLIT_MIN = env_int("MOCR_SPLIT_MIN", 600);
             long long rows_pending = 0;
             for (const Job& p : e->pending) rows_pending += p.n;
             int idle = 0;
@@ -1903,61 +1906,31 @@ static void prepare_and_decode(mocr_engine* e, const std::vector<PrepSource>& sr
         drive(e);
         return;
     }
-    struct Pipe {
-        std::mutex mu;
-        std::condition_variable cv;
-        int enqueued = 0;                          // chunks whose preparation has been enqueued (event recorded)
-        bool abort = false;
-        std::exception_ptr err;
-    } pipe;
     std::vector<hipEvent_t> ev(nchunks, nullptr);
     for (auto& x : ev) HIPCHECK(hipEventCreateWithFlags(&x, hipEventDisableTiming));
-    std::thread producer([&] {
-        try {
-            HIPCHECK(hipSetDevice(e->cfg.device));
-            for (int k = 0; k < nchunks; ++k) {
-                { std::lock_guard<std::mutex> lk(pipe.mu); if (pipe.abort) return; }
-                if (k >= 2) HIPCHECK(hipEventSynchronize(ev[k - 2]));      // the copy out of this pinned buffer has finished
-                prep_enqueue(e, srcs, views + (size_t)k * C, std::min(C, n - k * C), d_gray + (size_t)k * C * plane, k & 1, false, holds[k]);
-                HIPCHECK(hipEventRecord(ev[k], e->prep_stream));
-                { std::lock_guard<std::mutex> lk(pipe.mu); pipe.enqueued = k + 1; }
-                pipe.cv.notify_all();
-            }
-        } catch (...) {
-            std::lock_guard<std::mutex> lk(pipe.mu);
-            pipe.err = std::current_exception();
-            pipe.cv.notify_all();
-        }
-    });
-    auto finish = [&](bool aborting) {
-        { std::lock_guard<std::mutex> lk(pipe.mu); if (aborting) pipe.abort = true; }
-        producer.join();
+    auto cleanup = [&] {
         (void)hipStreamSynchronize(e->prep_stream);
         for (auto x : ev) if (x) (void)hipEventDestroy(x);
     };
-    try {
-        int next = 0;
-        for (;;) {
-            {
-                std::unique_lock<std::mutex> lk(pipe.mu);
-                if (pipe.err) std::rethrow_exception(pipe.err);
-                while (next < pipe.enqueued) { push_job(next, ev[next]); ++next; }
-            }
-            const bool busy = (e->cfg.dtype == MOCR_BF16) ? pump_once<bf16_t>(e) : pump_once<float>(e);
-            if (next == nchunks && !busy) break;
-            if (!busy) {                           // every lane idle, the next chunk not yet enqueued: wait for the producer
-                std::unique_lock<std::mutex> lk(pipe.mu);
-                pipe.cv.wait_for(lk, std::chrono::milliseconds(2), [&] { return pipe.enqueued > next || pipe.err; });
-            }
-        }
-        for (auto& L : e->lanes) HIPCHECK(hipStreamSynchronize(L.ctx.stream));
-    } catch (...) {
-        e->pending.clear();
-        for (auto& L : e->lanes) { L.active = false; L.jobs.clear(); (void)hipStreamSynchronize(L.ctx.stream); }
-        finish(true);
-        throw;
-    }
-    finish(false);
+    run_prep_pipeline(
+        nchunks,
+        [&](int k) {                                   // producer thread: pinned buffer k & 1 is free once chunk k - 2's copy has run
+            if (k == 0) HIPCHECK(hipSetDevice(e->cfg.device));
+            if (k >= 2) HIPCHECK(hipEventSynchronize(ev[k - 2]));
+        },
+        [&](int k) {                                   // producer thread
+            prep_enqueue(e, srcs, views + (size_t)k * C, std::min(C, n - k * C), d_gray + (size_t)k * C * plane, k & 1, false, holds[k]);
+            HIPCHECK(hipEventRecord(ev[k], e->prep_stream));
+        },
+        [&](int k) { push_job(k, ev[k]); },            // calling thread
+        [&] { return (e->cfg.dtype == MOCR_BF16) ? pump_once<bf16_t>(e) : pump_once<float>(e); },
+        [&] {                                          // either side failed: nothing stays queued, nothing stays in flight
+            e->pending.clear();
+            for (auto& L : e->lanes) { L.active = false; L.jobs.clear(); (void)hipStreamSynchronize(L.ctx.stream); }
+            cleanup();
+        });
+    for (auto& L : e->lanes) HIPCHECK(hipStreamSynchronize(L.ctx.stream));
+    cleanup();
 }
 
 int mocr_preprocess(mocr_engine* e, const mocr_image* images, int32_t n, uint8_t* out_gray) {

@@ -1,7 +1,7 @@
 """What does the vendor library reach on the encoder GEMM shapes?  (a yardstick only: the product
 never calls it)."""
 import torch, time, sys
-M = int(sys.argv[1]) if len(sys.argv) > 1 else 4096 * 197
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 256 * 197      # batch 256 (r03: 906 / 746 / 878 / 1059 TFLOP/s, profiles/r03_vendor_gemm.txt)
 for (N, K) in [(2304, 768), (768, 768), (3072, 768), (768, 3072)]:
     a = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
     w = torch.randn(N, K, device="cuda", dtype=torch.bfloat16)

@@ -1,9 +1,9 @@
 #!/bin/bash
 # The three rocprofv3 passes behind profiles/<round>_*.  Run on the GPU box from the repo root:
-#     bash tools/profile_passes.sh gpurun_out/prof_r02
+#     bash tools/profile_passes.sh gpurun_out/prof_r03
 # then, back in the build container:
-#     python tools/summarize_profiles.py --round r02 --rows 2560 --stats gpurun_out/prof_r02/trace \
-#            --fetch gpurun_out/prof_r02/fetch --write gpurun_out/prof_r02/write --note "..."
+#     python tools/summarize_profiles.py --round r03 --rows 2560 --stats gpurun_out/prof_r03/trace \
+#            --fetch gpurun_out/prof_r03/fetch --write gpurun_out/prof_r03/write --note "..."
 # One lane, no warm-up shape, timed region only: every launch belongs to a 2560-row internal batch decoding alone.
 # Counters are collected in passes of their own (FETCH_SIZE takes 3 of the 4 TCC slots), never together with a trace.
 set -e

@@ -33,6 +33,8 @@ CLASSES = [  # (substring of the kernel symbol, bench.py's class name)
     ("latent_attn_fp8_kernel<true>", "lat8_attn_self"), ("latent_attn_fp8_kernel<false>", "lat8_attn_cross"),
     ("dec_qqt_kernel", "dec_qqt"), ("enc_attn_mfma_kernel", "enc_attn_mfma"), ("layernorm_kernel", "layernorm"),
     ("dec_add_ln_kernel", "dec_add_ln"), ("dec_token_kernel", "dec_token"), ("gemm_wide2_kernel", "gemm_enc_layers(wide2)"),
+    # the persistent encoder GEMM by epilogue: <1 = bias (QKV), <2 = bias + GELU (FC1), <3 = bias + fp32 residual (O-proj and FC2)
+    ("gemm_pers_kernel<1", "gemm_enc_qkv"), ("gemm_pers_kernel<2", "gemm_enc_fc1"), ("gemm_pers_kernel<3", "gemm_enc_oproj+fc2"),
 ]
 
 
@@ -68,6 +70,14 @@ def algorithmic_bytes(c, rows, max_len=300):
         return rows * (197 * 1536 + 2 * 12 * 768 * 2)
     if c == "lat_attn_self":      # context grows 1..299: mean (max_len)/2 keys per launch
         return rows * (max_len / 2 * 1536 + 2 * 12 * 768 * 2)
+    # encoder layer GEMMs (M = rows * 197): bf16 operands once, output once (+ the fp32 residual read for O-proj / FC2)
+    M = rows * 197
+    if c == "gemm_enc_qkv":
+        return (M * 768 + 2304 * 768) * 2 + M * 2304 * 2
+    if c == "gemm_enc_fc1":
+        return (M * 768 + 3072 * 768) * 2 + M * 3072 * 2
+    if c == "gemm_enc_oproj+fc2":  # equal launch counts: the mean of the two
+        return ((M * 768 + 768 * 768) * 2 + (M * 3072 + 768 * 3072) * 2) / 2 + 2 * M * 768 * 4
     return None
 
 
