@@ -164,6 +164,10 @@ class MangaOcr:
             if len(vocab) != spec.vocab:
                 raise ValueError(f"vocab.txt has {len(vocab)} entries, config says {spec.vocab}")
         self.spec, self.vocab = spec, vocab
+        # what the checkpoint's config.json asked of generate() and this engine ignores (greedy decode only): the reference
+        # application's recogniser would honour e.g. num_beams=4 / no_repeat_ngram_size=3, so on such a checkpoint the
+        # strings can differ from the pip package's; {} when there is nothing to report
+        self.ignored_generation_config = dict(getattr(spec, "ignored_generation", ()))
         if devices is not None and len(devices) > 1:
             from .multi import MultiGpuEngine
             max_batch = int(max_batch or 2048)

@@ -20,7 +20,7 @@ from __future__ import annotations
 import json
 import os
 import re
-from dataclasses import dataclass, asdict
+from dataclasses import dataclass, field, replace, asdict
 from typing import Dict, List, Tuple
 
 import numpy as np
@@ -43,6 +43,10 @@ class ModelSpec:
     start_id: int = 2          # [CLS] = decoder_start_token_id
     eos_id: int = 3            # [SEP]
     pad_id: int = 0            # [PAD]
+    # generation settings a checkpoint's config.json asked for and this engine does NOT honour (it decodes greedily, as
+    # BASELINE.json's north_star fixes): e.g. (("num_beams", 4), ("no_repeat_ngram_size", 3)).  Readable by callers via
+    # MangaOcr.ignored_generation_config; empty for synthetic weights and for greedy checkpoints.
+    ignored_generation: tuple = field(default=(), compare=False)
 
     @property
     def grid(self) -> int:
@@ -250,6 +254,7 @@ def spec_from_hf_config(cfg: dict) -> ModelSpec:
         warnings.warn("checkpoint config asks for non-greedy generation " + repr(non_greedy) +
                       "; this engine implements greedy decode (generate(do_sample=False, num_beams=1)) and ignores it",
                       RuntimeWarning, stacklevel=2)
+        spec = replace(spec, ignored_generation=tuple(sorted(non_greedy.items())))
     return spec
 
 

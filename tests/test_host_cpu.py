@@ -82,7 +82,10 @@ def test_checkpoint_key_renames_and_config_checks():
     # the published config carries its training script's beam-search defaults [RECALL]; north_star fixes greedy:
     # the loader says so once and goes on
     with pytest.warns(RuntimeWarning, match="greedy"):
-        assert spec_from_hf_config({**cfg, "num_beams": 4, "no_repeat_ngram_size": 3, "length_penalty": 2.0}) == DEFAULT_SPEC
+        beam = spec_from_hf_config({**cfg, "num_beams": 4, "no_repeat_ngram_size": 3, "length_penalty": 2.0})
+        assert beam == DEFAULT_SPEC          # the model is the same; what the engine will NOT do is kept for the caller to read
+        assert dict(beam.ignored_generation) == {"num_beams": 4, "no_repeat_ngram_size": 3, "length_penalty": 2.0}
+        assert DEFAULT_SPEC.ignored_generation == ()
     with pytest.raises(ValueError):
         spec_from_hf_config({**cfg, "encoder": {"hidden_act": "gelu_new"}})
 
