@@ -28,6 +28,8 @@ constexpr int PERS_LDS = 160 * 1024;      // four 32 KiB ring slots + 32 KiB tha
 
 // SPLIT_DMA: the LDS-DMA of a K-tile is requested by waves 0-3 alone (8 pieces each; those waves then never have a
 // store in their queue) instead of by all eight waves (4 pieces each).
+// (r03, measured and dropped: the requests as `buffer_load_dwordx4 ... offen lds` - descriptor and offsets in SGPRs, no
+// VALU address arithmetic per request: QKV without epilogue 147 -> 174 us, the other three GEMMs unchanged.)
 template <int EPI, bool SPLIT_DMA>
 __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
     constexpr int BM = 256, BN = 256, WN = 4;
