@@ -17,6 +17,14 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
     return *reinterpret_cast<bf16_t*>(&b);
 }
 
+// two floats -> one dword of two bf16 (ONE v_cvt_pk_bf16_f32; lo in the low half)
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    const bf16x2_t v = __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t);
+    return *reinterpret_cast<const unsigned*>(&v);
+}
+
 // ---- typed element access: T is float (parity mode) or bf16_t (bf16 storage) ------------------
 template <typename T> struct elem;
 template <> struct elem<float> {

@@ -373,7 +373,30 @@ void launch_gemm_wide2_t(mocr_engine* e, const GemmParams& p0) {
 
 // The persistent kernel (kernels_gemm_pers.h): one block per CU walks its share of the 256 x 256 tiles.  `blocks` = 0:
 // one block per CU (a multiple of 8, at most one per tile); a test may ask for fewer blocks (longer tile sequences).
-template <int EPI, bool SPLIT_DMA>
+// The strip schedule of the persistent kernel (kernels_gemm_pers.h, STRIP): rows per strip for a grid of `grid` blocks,
+// 0 when the grid cannot hold a strip.  Host mirror of the kernel's arithmetic.
+static int pers_strip_rows(int M, int ntn, int grid) {
+    const int slots = grid >> 3, spx = slots / ntn;
+    const int nstrips = 8 * spx + (8 * (slots - spx * ntn)) / ntn;
+    if (nstrips <= 0) return 0;
+    const int U = (M + 15) >> 4;
+    return ((U + nstrips - 1) / nstrips) * 16;
+}
+
+// Rounds of 256 x 256 tiles the slowest block walks: tile list (XCD chunks dealt round-robin) vs strips (a half tile costs
+// ~0.6 of a tile: one wave per SIMD multiplies).
+static bool pers_strip_wins(int M, int ntn, int grid) {
+    const int ntiles = ((M + 255) / 256) * ntn;
+    if (ntiles < 2 * grid) return false;
+    const int chunk = (ntiles + 7) / 8, per_block = (chunk + (grid >> 3) - 1) / (grid >> 3);
+    const int R = pers_strip_rows(M, ntn, grid);
+    if (!R) return false;
+    const int rem = R & 255;
+    const double strip_cost = (R >> 8) + (rem == 0 ? 0.0 : rem <= 128 ? 0.6 : 1.0);
+    return strip_cost <= 0.95 * per_block;
+}
+
+template <int EPI, bool SPLIT_DMA, bool PAIR = false, bool STRIP = false>
 void launch_gemm_pers_t(mocr_engine* e, const GemmParams& p0, int blocks) {
     GemmParams p = p0;
     p.ntn = p.N / 256;
@@ -383,17 +406,28 @@ void launch_gemm_pers_t(mocr_engine* e, const GemmParams& p0, int blocks) {
     grid = std::max(8, grid / 8 * 8);
     static const int stagger_env = env_int("MOCR_GEMM_STAGGER", 0);
     p.stagger = stagger_env;
-    hipLaunchKernelGGL((gemm_pers_kernel<EPI, SPLIT_DMA>), dim3(grid), dim3(512), PERS_LDS, e->stream, p);
+    hipLaunchKernelGGL((gemm_pers_kernel<EPI, SPLIT_DMA, PAIR, STRIP>), dim3(grid), dim3(512), PERS_LDS, e->stream, p);
     HIPCHECK(hipGetLastError());
 }
 
-template <bool SPLIT_DMA>
-void launch_gemm_pers(mocr_engine* e, const GemmParams& p, int epi, int blocks) {
+// strip: 0 tile list, 1 strips, -1 whichever walks fewer rounds (EPI_BIAS_RESID only; the other epilogues keep the list)
+template <bool SPLIT_DMA, bool PAIR = false>
+void launch_gemm_pers(mocr_engine* e, const GemmParams& p, int epi, int blocks, int strip = 0) {
     if (p.k_per_split % 64 || p.k_per_split < 128) throw ArgError{"persistent gemm: K must be a multiple of 64, >= 128", MOCR_ERR_ARG};
+    if constexpr (SPLIT_DMA && PAIR) {
+        if (epi == EPI_BIAS_RESID && strip) {
+            const int ntn = p.N / 256, ntiles = ((p.M + 255) / 256) * ntn;
+            const int grid = std::max(8, std::min(blocks > 0 ? blocks : e->num_cus, (ntiles + 7) / 8 * 8) / 8 * 8);
+            if (strip > 0 ? pers_strip_rows(p.M, ntn, grid) > 0 : pers_strip_wins(p.M, ntn, grid)) {
+                launch_gemm_pers_t<EPI_BIAS_RESID, true, true, true>(e, p, blocks);
+                return;
+            }
+        }
+    }
     switch (epi) {
-        case EPI_BIAS: launch_gemm_pers_t<EPI_BIAS, SPLIT_DMA>(e, p, blocks); break;
-        case EPI_BIAS_GELU: launch_gemm_pers_t<EPI_BIAS_GELU, SPLIT_DMA>(e, p, blocks); break;
-        case EPI_BIAS_RESID: launch_gemm_pers_t<EPI_BIAS_RESID, SPLIT_DMA>(e, p, blocks); break;
+        case EPI_BIAS: launch_gemm_pers_t<EPI_BIAS, SPLIT_DMA, PAIR>(e, p, blocks); break;
+        case EPI_BIAS_GELU: launch_gemm_pers_t<EPI_BIAS_GELU, SPLIT_DMA, PAIR>(e, p, blocks); break;
+        case EPI_BIAS_RESID: launch_gemm_pers_t<EPI_BIAS_RESID, SPLIT_DMA, PAIR>(e, p, blocks); break;
         default: throw ArgError{"persistent gemm: unsupported epilogue", MOCR_ERR_ARG};
     }
 }
@@ -452,10 +486,20 @@ void gemm(mocr_engine* e, const char* name, const void* A, int lda, const void* 
     const double bytes = ((double)M * K + (double)N * K) * sizeof(T) + (double)M * N * out_b * (epi == EPI_SLAB ? split : 1) +
                          (epi == EPI_BIAS_RESID ? (double)M * N * 4 : 0);
     ProfScope ps(e, name, 2.0 * M * N * K * ybatch, bytes * ybatch);
-    if (tile == 4096) launch_gemm_pers<true>(e, p, epi, 0);
-    else if (tile == 4097) launch_gemm_pers<true>(e, p, epi, 8);    // test hook: 8 blocks walk all the tiles
+    // one barrier per two K-tiles for the fp32-residual GEMMs (r03, M = 50,432: O-proj 137 -> 129 us, FC2 305 -> 302; the
+    // bf16-output GEMMs lose with it: QKV 175 -> 208 us)
+    // 4099 / 4100: the strip schedule forced (whole grid / 8 blocks) - test hooks like 4097
+    if (tile == 4096 || tile == 4097 || tile == 4099 || tile == 4100) {
+        const int blocks = (tile == 4097 || tile == 4100) ? 8 : 0;     // 4097: test hook, 8 blocks walk all the tiles
+        static const int strip_env = env_int("MOCR_GEMM_STRIP", -1);
+        const int strip = tile >= 4099 ? 1 : tile == 4097 ? 0 : strip_env;
+        if (epi == EPI_BIAS_RESID) launch_gemm_pers<true, true>(e, p, epi, blocks, strip);
+        else launch_gemm_pers<true, false>(e, p, epi, blocks);
+    }
 #ifdef MOCR_EXPERIMENTS
     else if (tile == 4098) launch_gemm_pers<false>(e, p, epi, 0);   // experiment: every wave requests LDS-DMA
+    else if (tile == 4101) launch_gemm_pers<true, true>(e, p, epi, 0);    // experiment: one barrier per two K-tiles
+    else if (tile == 4102) launch_gemm_pers<true, true>(e, p, epi, 8);
     else if (tile == 2048) launch_gemm_wide2(e, p, epi);
     else if (tile == 1024) launch_gemm_wide<4>(e, p, epi);
     else if (tile == 512) launch_gemm_wide<2>(e, p, epi);
@@ -485,12 +529,23 @@ void enc_attention(mocr_engine* e, const void* qkv, void* ctx, int n, int impl) 
     const double bytes = (double)n * S * e->D * 4 * sizeof(T);
     if (impl == 1 && sizeof(T) == 2) {
         ProfScope ps(e, "enc_attn_mfma", flops, bytes);
+        // a few crops: two / four blocks per (image, head) share its thirteen 16-query units while n * H blocks would leave
+        // most of the chip idle (three blocks fit a CU)
+        const long long blocks = (long long)n * H;
+        const int ysplit = blocks * 4 <= 2LL * e->num_cus ? 4 : blocks * 2 <= 2LL * e->num_cus ? 2 : 1;
+        static const int ablate2_env = env_int("MOCR_ENC_ATTN_ABLATE", 0);
+        hipLaunchKernelGGL(enc_attn2_kernel, dim3(n * H, ysplit), dim3(256), EA2_LDS, e->stream,
+                           reinterpret_cast<const bf16_t*>(qkv), reinterpret_cast<bf16_t*>(ctx), H, 3 * e->D, e->D, ablate2_env);
+#ifdef MOCR_EXPERIMENTS
+    } else if (impl == 2 && sizeof(T) == 2) {          // r01-r02 kernel (K / V staged through registers), A/B only
+        ProfScope ps(e, "enc_attn_mfma_r02", flops, bytes);
         constexpr int lds = ENC_SP * 128 + 64 * ENC_VT_LD * 2;
-        // a few crops: two blocks per (image, head), four query tiles each, while n * H blocks would cover less than half the chip
         static const int qsplit_env = env_int("MOCR_ENC_ATTN_QSPLIT", 1);
         const int ysplit = (qsplit_env && n * H * 2 <= e->num_cus) ? 2 : 1;
+        static const int ablate_env = env_int("MOCR_ENC_ATTN_ABLATE", 0);
         hipLaunchKernelGGL(enc_attn_mfma_kernel, dim3(n * H, ysplit), dim3(256), lds, e->stream,
-                           reinterpret_cast<const bf16_t*>(qkv), reinterpret_cast<bf16_t*>(ctx), H, 3 * e->D, e->D);
+                           reinterpret_cast<const bf16_t*>(qkv), reinterpret_cast<bf16_t*>(ctx), H, 3 * e->D, e->D, ablate_env);
+#endif
     } else {
         ProfScope ps(e, "enc_attn_simple", flops, bytes);
         constexpr int lds = (200 * 65 + 200 * 64 + 4 * 64 + 4 * 256) * 4;
@@ -1010,7 +1065,10 @@ template <typename T> void init_kernel_attrs() {
     set_max_lds(gemm_kernel<T, 64, 64, EPI_BIAS_F32, 4>, 2 * l64);
     set_max_lds(gemm_kernel<T, 64, 64, EPI_ARGMAX, 4>, 2 * l64);
     set_max_lds(enc_attn_simple_kernel<T>, (200 * 65 + 200 * 64 + 4 * 64 + 4 * 256) * 4);
+    set_max_lds(enc_attn2_kernel, EA2_LDS);
+#ifdef MOCR_EXPERIMENTS
     set_max_lds(enc_attn_mfma_kernel, ENC_SP * 128 + 64 * ENC_VT_LD * 2);
+#endif
     set_max_lds(dec_qqt_kernel, 160 * 1024);
 #ifdef MOCR_EXPERIMENTS
     constexpr int l256 = 3 * (256 + 128) * 128;
@@ -1027,7 +1085,11 @@ template <typename T> void init_kernel_attrs() {
     set_max_lds(gemm_pers_kernel<EPI_BIAS, true>, PERS_LDS);
     set_max_lds(gemm_pers_kernel<EPI_BIAS_GELU, true>, PERS_LDS);
     set_max_lds(gemm_pers_kernel<EPI_BIAS_RESID, true>, PERS_LDS);
+    set_max_lds(gemm_pers_kernel<EPI_BIAS_RESID, true, true>, PERS_LDS);
+    set_max_lds(gemm_pers_kernel<EPI_BIAS_RESID, true, true, true>, PERS_LDS);
 #ifdef MOCR_EXPERIMENTS
+    set_max_lds(gemm_pers_kernel<EPI_BIAS, true, true>, PERS_LDS);
+    set_max_lds(gemm_pers_kernel<EPI_BIAS_GELU, true, true>, PERS_LDS);
     set_max_lds(gemm_pers_kernel<EPI_BIAS, false>, PERS_LDS);
     set_max_lds(gemm_pers_kernel<EPI_BIAS_GELU, false>, PERS_LDS);
     set_max_lds(gemm_pers_kernel<EPI_BIAS_RESID, false>, PERS_LDS);

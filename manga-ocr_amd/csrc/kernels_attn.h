@@ -11,6 +11,11 @@
 #pragma once
 #include "common.h"
 
+// LDS byte address (what ds_* instructions take) of a pointer into the dynamic LDS array
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const char*)p;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Encoder attention, VALU.  One block per (image, head); K as fp32 [S][65] and V as fp32 [S][64]
 // in LDS.  Each wave owns every 4th query row: lane j scores keys j, j+64, ...; lane d accumulates
@@ -88,12 +93,18 @@ __global__ __launch_bounds__(256) void enc_attn_simple_kernel(const T* __restric
 //   key = 16s + 8(j>>2) + 4(lane>>5) + (j&3); the V^T fragment is gathered in that same order.
 // ------------------------------------------------------------------------------------------------
 #define ENC_S 197
+#ifdef MOCR_EXPERIMENTS      // r01-r02 kernel, kept for A/B (impl code 2 of mocr_op_enc_attention in the experiments build)
 #define ENC_SP 224
 #define ENC_VT_LD 228
 
 __global__ __launch_bounds__(256, 2) void enc_attn_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
-                                                            int H, int ld_qkv, int ld_ctx) {
+                                                            int H, int ld_qkv, int ld_ctx, int ablate_arg = 0) {
     constexpr int DH = 64;
+#ifdef MOCR_EXPERIMENTS
+    const int ablate = ablate_arg;          // diagnostics (MOCR_ENC_ATTN_ABLATE): 1 = no query tiles (staging only), 2 = no K / V staging
+#else
+    constexpr int ablate = 0;
+#endif
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sK = smem;                                              // 224 * 128 B
     bf16_t* sVt = reinterpret_cast<bf16_t*>(smem + ENC_SP * 128); // 64 * 228 * 2 B
@@ -114,6 +125,7 @@ __global__ __launch_bounds__(256, 2) void enc_attn_mfma_kernel(const bf16_t* __r
         for (int s = 0; s < 4; ++s)
             qpre[ti][s] = *reinterpret_cast<const bf16x8*>(base + (size_t)qc * ld_qkv + s * 16 + hh * 8);
     }
+    if (!(ablate & 2))
     // ---- stage K (swizzled rows) and V^T; zero the padding keys 197..223(227).  ALL global loads of a thread are issued
     // before the first LDS store (r02): left as a rolled loop the seven + four load -> store round trips ran one
     // after the other, a global-load latency each (126 -> 97 us per 3072-block launch at batch 256)
@@ -157,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void enc_attn_mfma_kernel(const bf16_t* __r
     __syncthreads();
 
     // gridDim.y = 2 (a few crops: n * H blocks would leave most CUs idle): block y takes the query tiles 4 y .. 4 y + 3
-    for (int qt = wave + (gridDim.y > 1 ? 4 * (int)blockIdx.y : 0); qt < ENC_SP / 32; qt += 4 * (int)gridDim.y) {
+    for (int qt = wave + (gridDim.y > 1 ? 4 * (int)blockIdx.y : 0); qt < ((ablate & 1) ? 0 : ENC_SP / 32); qt += 4 * (int)gridDim.y) {
         const int q = qt * 32 + r32;                // (padded queries are computed from a clamped row, not stored)
         // B operand of S^T = K.Q^T : lane holds Q[q][16s + 8hh .. +7]
         bf16x8 qf[4];
@@ -238,6 +250,200 @@ __global__ __launch_bounds__(256, 2) void enc_attn_mfma_kernel(const bf16_t* __r
                     elem<bf16_t>::st4(orow + dt * 32 + 8 * g + 4 * hh, o4);   // d = 32dt + 8g + 4hh + (r&3)
                 }
         }
+    }
+}
+
+#endif  // MOCR_EXPERIMENTS
+
+// ------------------------------------------------------------------------------------------------
+// enc_attn2_kernel (r03): encoder self-attention whose K and V arrive by LDS-DMA.
+//   r02's kernel above staged K and V through registers (V with a scatter transpose: 32 ds_write_b32 per thread) and
+//   spent 37 of its 94 us per batch-256 launch there, NOT overlapped with the other block's query tiles - staging and
+//   softmax both live on the VALU (r03 ablations: staging alone 37 us, query tiles alone 64 us, both 94 us).  Here:
+//   * K and V of the head are copied ROW-MAJOR ([208 keys][128 B], 16-byte chunk c of row r at chunk c ^ ((r>>1)&7),
+//     applied on the source address) by global_load_lds: 13 one-KiB requests per wave, no register, no VALU; 52 KiB per
+//     block, so three blocks share a CU and one block's copy runs under the others' query tiles;
+//   * S^T = K.Q^T on v_mfma_f32_16x16x32_bf16 per 16-query unit (13 units for 197 queries, 13 key tiles of 16 for 197
+//     keys: 5 % padding each way instead of 14 %): a lane ends up with one query's scores for keys 4g .. 4g+3 of every
+//     key tile - softmax is lane-local plus two exchanges across the four lane groups;
+//   * O^T = V^T.P^T: the probabilities of two key tiles, as they lie in the registers, ARE the B operand (its 32 k-slots
+//     then stand for keys {4g+j of tile 2u, 4g+j of tile 2u+1}); the A operand follows the same key order by reading V
+//     column-wise with ds_read_b64_tr_b16: rows 32u + 4g .. +3 and 32u + 16 + 4g .. +3 of the row-major image - no
+//     transposed copy of V anywhere.
+//   Keys 197 .. 207: rows 197-199 are whatever follows in the QKV matrix (finite; the buffers are padded), rows 200-207 are
+//   zeroed once; their scores are set to -inf, so their probabilities are exactly 0.
+// ------------------------------------------------------------------------------------------------
+#define EA2_ROWS 208
+#define EA2_LDS (2 * EA2_ROWS * 128)
+
+__global__ __launch_bounds__(256, 3) void enc_attn2_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
+                                                        int H, int ld_qkv, int ld_ctx, int ablate_arg = 0) {
+    constexpr int DH = 64, KT = 13;
+#ifdef MOCR_EXPERIMENTS
+    const int ablate = ablate_arg;      // diagnostics (MOCR_ENC_ATTN_ABLATE): 1 no S product, 2 no exp, 4 no P.V, 8 no K / V copy, 16 no stores, 32 no query loads after the first
+#else
+    constexpr int ablate = 0;
+#endif
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const sK = smem;
+    char* const sV = smem + EA2_ROWS * 128;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int D = H * DH;
+    const bf16_t* base = qkv + (size_t)b * ENC_S * ld_qkv + h * DH;
+    if (ablate >> 8) {                      // experiment: the three blocks a CU starts with begin (ablate >> 8) x 0.5 us apart
+        const int phase = (int)(blockIdx.x >> 8);
+        if (phase < 3)
+            for (int i = 0; i < phase * (ablate >> 8); ++i) __builtin_amdgcn_s_sleep(16);
+    }
+
+    // ---- K and V: 25 pieces of 8 rows x 128 B each (rows 0 .. 199), lane -> row lane>>3, physical chunk lane&7
+    {
+        const int prow = lane >> 3, pch = lane & 7;
+        for (int pc = wave; pc < ((ablate & 8) ? 0 : 25); pc += 4) {
+            const int row = pc * 8 + prow;
+            const int c = pch ^ ((row >> 1) & 7);
+            const bf16_t* src = base + (size_t)row * ld_qkv + c * 8;
+            glds16(src + D, sK + pc * 1024);
+            glds16(src + 2 * D, sV + pc * 1024);
+        }
+        if (tid < 64) {                                              // rows 200 .. 207: never copied
+            *reinterpret_cast<uint4*>(sK + 200 * 128 + tid * 16) = make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(sV + 200 * 128 + tid * 16) = make_uint4(0, 0, 0, 0);
+        }
+    }
+    // this wave's 16-query units: slot, slot + 4 * gridDim.y, ... (the unit count per slot differs by one: the slot a
+    // wave takes rotates with the block, so that the SIMDs of a CU - which host the same wave number of three blocks -
+    // get equal work)
+    const int nslots = 4 * (int)gridDim.y;
+    const int slot = ((wave + (int)blockIdx.x) & 3) + 4 * (int)blockIdx.y;
+    // first unit's queries: requested before the wait for the copies
+    auto load_q = [&](int unit, bf16x8 (&qf)[2]) {
+        const int qq = unit * 16 + l15;
+        const bf16_t* qrow = base + (size_t)(qq < ENC_S ? qq : ENC_S - 1) * ld_qkv + 8 * g;
+        qf[0] = *reinterpret_cast<const bf16x8*>(qrow);
+        qf[1] = *reinterpret_cast<const bf16x8*>(qrow + 32);
+    };
+    bf16x8 qf[2];
+    if (slot < KT) load_q(slot, qf);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // transposed block reads of V: lane 4q+p of a 16-lane group supplies row q, columns 4p .. 4p+3 of a 4 x 16 block.
+    // Row 32u + 4g + q (and the same + 16): its swizzle term ((row >> 1) & 7) does not depend on u, so a lane needs ONE
+    // address per 16-column tile for the whole kernel; u and the + 16 rows are immediate offsets of the instruction.
+    const int q4 = l15 >> 2, p4 = l15 & 3;
+    unsigned vaddr[4];
+    {
+        const int row = 4 * g + q4, sw = (row >> 1) & 7;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+            vaddr[dt] = lds_addr(sV) + row * 128 + (((2 * dt + (p4 >> 1)) ^ sw) << 4) + (p4 & 1) * 8;
+    }
+    // K rows 16 kt + l15: likewise one swizzle term per lane; kt is an immediate offset
+    const int ksw = (l15 >> 1) & 7;
+    const char* const kp0 = sK + l15 * 128 + ((g ^ ksw) << 4);
+    const char* const kp1 = sK + l15 * 128 + (((4 + g) ^ ksw) << 4);
+    for (int unit = slot; unit < KT; unit += nslots) {
+        const int q = unit * 16 + l15;
+        // ---- S^T[key][q] over the 13 key tiles: lane (q = l15, g) gets keys 16 kt + 4g + r
+        f32x4 st[KT];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(kp0 + kt * 2048);
+            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(kp1 + kt * 2048);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            if (ablate & 1) { st[kt] = f32x4{(float)kt, 1.f, 2.f, (float)l15}; continue; }
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, qf[0], acc, 0, 0, 0);
+            st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, qf[1], acc, 0, 0, 0);
+        }
+        // the next unit's queries: requested now, used after this unit's softmax and P.V
+        bf16x8 qn[2] = {qf[0], qf[1]};
+        if (unit + nslots < KT && !(ablate & 32)) load_q(unit + nslots, qn);
+        // ---- softmax over the 197 keys of this lane's query (52 here, the rest in the lanes l15 + 16, + 32, + 48)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (192 + 4 * g + r >= ENC_S) st[12][r] = -INFINITY;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kt][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float c0 = 0.125f * 1.44269504088896340736f;   // scale * log2(e)
+        const float mb = mx * c0;
+        float sum = 0.f;
+        unsigned pk[KT][2];                                   // probabilities as bf16 pairs
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            float e[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                e[r] = (ablate & 2) ? st[kt][r] * c0 - mb : __builtin_amdgcn_exp2f(st[kt][r] * c0 - mb);      // exp2(-inf) = 0 for the padded keys
+                sum += e[r];
+            }
+            pk[kt][0] = pack_bf16x2(e[0], e[1]);
+            pk[kt][1] = pack_bf16x2(e[2], e[3]);
+        }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        // ---- O^T[d][q] += V^T[d][key] P^T[key][q], two key tiles (32 k-slots) per MFMA
+        f32x4 oacc[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < ((ablate & 4) ? 0 : 7); ++u) {
+            union { uint4 w; bf16x8 v; } pf;
+            pf.w = make_uint4(pk[2 * u][0], pk[2 * u][1], u < 6 ? pk[2 * u + 1][0] : 0u, u < 6 ? pk[2 * u + 1][1] : 0u);
+            uint2 lo[4], hi[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo[dt]) : "v"(vaddr[dt]), "i"(4096 * u) : "memory");
+                if (u < 6) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi[dt]) : "v"(vaddr[dt]), "i"(4096 * u + 2048) : "memory");
+                else hi[dt] = make_uint2(0u, 0u);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]));
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                union { uint4 w; bf16x8 v; } vf;
+                vf.w = make_uint4(lo[dt].x, lo[dt].y, hi[dt].x, hi[dt].y);
+                oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf.v, oacc[dt], 0, 0, 0);
+            }
+        }
+        // ---- ctx[q][64 h + d] = O^T / sum.  A lane holds d = 16 dt + 4 g + r of its query; the four lanes of a query
+        // (l15 + 16 g) exchange 4 x 4 blocks (dt <-> g: v_permlane32_swap, then v_permlane16_swap) so that lane g ends up
+        // with d = 16 g .. 16 g + 15: two 16-byte stores per lane instead of four 8-byte ones (r03: the 8-byte stores -
+        // 16 rows x 32 B per instruction - cost 22 of the launch's 89 us at batch 256)
+        {
+            const float inv = 1.0f / sum;
+            unsigned x[4][2];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                x[dt][0] = pack_bf16x2(oacc[dt][0] * inv, oacc[dt][1] * inv);
+                x[dt][1] = pack_bf16x2(oacc[dt][2] * inv, oacc[dt][3] * inv);
+            }
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+#pragma unroll
+                for (int d0 = 0; d0 < 2; ++d0) {          // lanes 32-63 of x[d0] <-> lanes 0-31 of x[d0 + 2]
+                    auto r = __builtin_amdgcn_permlane32_swap(x[d0][w], x[d0 + 2][w], false, false);
+                    x[d0][w] = r[0]; x[d0 + 2][w] = r[1];
+                }
+#pragma unroll
+                for (int d0 = 0; d0 < 4; d0 += 2) {       // odd 16-lane rows of x[d0] <-> even rows of x[d0 + 1]
+                    auto r = __builtin_amdgcn_permlane16_swap(x[d0][w], x[d0 + 1][w], false, false);
+                    x[d0][w] = r[0]; x[d0 + 1][w] = r[1];
+                }
+            }
+            if (q < ENC_S && !(ablate & 16)) {
+                bf16_t* orow = ctx + ((size_t)b * ENC_S + q) * ld_ctx + h * DH + 16 * g;
+                *reinterpret_cast<uint4*>(orow) = make_uint4(x[0][0], x[0][1], x[1][0], x[1][1]);
+                *reinterpret_cast<uint4*>(orow + 8) = make_uint4(x[2][0], x[2][1], x[3][0], x[3][1]);
+            }
+        }
+        qf[0] = qn[0]; qf[1] = qn[1];
     }
 }
 

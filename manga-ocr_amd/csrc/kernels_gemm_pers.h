@@ -30,8 +30,15 @@ constexpr int PERS_LDS = 160 * 1024;      // four 32 KiB ring slots + 32 KiB tha
 // store in their queue) instead of by all eight waves (4 pieces each).
 // (r03, measured and dropped: the requests as `buffer_load_dwordx4 ... offen lds` - descriptor and offsets in SGPRs, no
 // VALU address arithmetic per request: QKV without epilogue 147 -> 174 us, the other three GEMMs unchanged.)
-template <int EPI, bool SPLIT_DMA>
+// PAIR: ONE barrier per two K-tiles.  K-tile 2p runs barrier-free on fragments and data the barrier of K-tile 2p - 1
+// already proved landed; the barrier in the middle of K-tile 2p + 1 proves K-tiles 2p + 2 and 2p + 3 and hands the slots of
+// 2p and 2p + 1 back (refilled right behind it and at the head of the next K-tile).  Two K-tiles in flight instead of
+// three.
+// STRIP (with PAIR, EPI_BIAS_RESID: the N = 768 GEMMs): the block owns a STRIP of rows of ONE 256-column slice instead of
+// whole 256-row tiles of a shared list - see the schedule below.
+template <int EPI, bool SPLIT_DMA, bool PAIR = false, bool STRIP = false>
 __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
+    static_assert(!STRIP || (PAIR && SPLIT_DMA), "the strip schedule's half tiles rely on the PAIR loop's count-free waits");
     constexpr int BM = 256, BN = 256, WN = 4;
     constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64, STAGE = A_BYTES + B_BYTES;   // 32 KiB per 32-deep K-tile
     constexpr int RING = 4 * STAGE;                                                  // 128 KiB; + 32 KiB spare = 160 KiB
@@ -52,14 +59,48 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
 
     // this block's tiles: XCD (blockIdx & 7) owns a contiguous chunk of the tile list; its blocks take the chunk's tiles
     // round-robin, so the tiles in flight on one XCD at any time are neighbours (shared A row-panels / W slices in L2)
+    //
+    // STRIP: at M = 50,432 the N = 768 GEMMs have 591 tiles for 256 CUs - three rounds for 2.31 rounds of work, and every CU
+    // reaches its HBM-bound fp32 epilogue (256 KiB read + 256 KiB written) in the same microseconds.  Instead the rows are
+    // cut into `nstrips` strips of whole 16-row units (85 strips of 592 / 608 rows there), a block owns one strip of one
+    // 256-column slice and walks it as 256-row tiles plus ONE half tile for a remainder of up to 128 rows: only the waves
+    // that own the tile's rows 128..255 (waves 4-7) multiply it - one wave per SIMD, half the matrix work of a tile - while
+    // waves 0-3 keep requesting the LDS-DMA and meeting the barriers.  The half tile comes first, in the middle or last by
+    // strip number, so that the blocks of the chip reach their epilogues at different times.  The `ntn` blocks of a strip
+    // are neighbours in one XCD's block order (they read the same A row-panel at the same time).
     const int ntiles = p.ntm * p.ntn;
-    int tile, tile_end;
-    const int tstride = gridDim.x >> 3;
-    {
+    int tile, tile_end, tstride;
+    int s_rs = 0, s_re = 0, s_n0 = 0, s_rem = 0, s_hpos = -1;      // STRIP: rows [s_rs, s_re), column, remainder rows, half tile's position
+    if constexpr (!STRIP) {
+        tstride = gridDim.x >> 3;
         const int xcd = blockIdx.x & 7, q = ntiles >> 3, r = ntiles & 7;
         const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
         tile = start + (blockIdx.x >> 3);
         tile_end = start + (xcd < r ? q + 1 : q);
+    } else {
+        const int slots = gridDim.x >> 3, xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+        const int spx = slots / p.ntn, used = spx * p.ntn;          // whole strips inside one XCD's blocks
+        int strip, col;
+        if (k < used) { strip = xcd * spx + k / p.ntn; col = k - (k / p.ntn) * p.ntn; }
+        else { const int j = (k - used) * 8 + xcd; strip = 8 * spx + j / p.ntn; col = j - (j / p.ntn) * p.ntn; }   // the XCDs' left-over blocks
+        const int nstrips = 8 * spx + (8 * (slots - used)) / p.ntn;
+        tile = 0; tile_end = 0; tstride = 1;
+        if (strip < nstrips) {
+            const int U = (p.M + 15) >> 4, base = U / nstrips, extra = U - base * nstrips;
+            const int u0 = strip * base + min(strip, extra), nu = base + (strip < extra ? 1 : 0);
+            s_rs = u0 * 16; s_re = min(p.M, (u0 + nu) * 16);
+            if (s_re > s_rs) {
+                const int R = s_re - s_rs;
+                s_rem = R & 255;
+                tile_end = (R >> 8) + (s_rem ? 1 : 0);
+                if (s_rem && s_rem <= 128) {
+                    const int v = strip % 3;
+                    s_hpos = v == 0 ? tile_end - 1 : v == 1 ? 0 : tile_end >> 1;
+                    if (s_hpos == 0 && s_rs < 128) s_hpos = tile_end > 1 ? tile_end - 1 : -1;      // a half tile starts 128 rows above its rows
+                }
+                s_n0 = col * BN;
+            }
+        }
     }
     if (tile >= tile_end) return;
     // Experiment knob (MOCR_GEMM_STAGGER, x 1024 cycles): the four CUs that are neighbours in an XCD's block order start a
@@ -70,7 +111,22 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
     }
     const int nt = p.k_per_split / 32;            // even, >= 4 (checked on the host)
     const size_t a_row = (size_t)p.lda * 2, w_row = (size_t)p.ldw * 2;
-    const bool guard = (p.M & (BM - 1)) != 0;
+    const bool guard = STRIP || (p.M & (BM - 1)) != 0;
+    // tile t of this block (a global tile index; STRIP: the t-th tile of the strip): first row of the 256-row window,
+    // first column, the rows [lo, hi) it owns, half tile or not
+    auto tile_desc = [&](int t, int& m0, int& n0, int& lo, int& hi, bool& half) {
+        if constexpr (!STRIP) {
+            int tm, tn;
+            gemm_tile_of(p, t, tm, tn);
+            m0 = tm * BM; n0 = tn * BN; lo = m0; hi = min(p.M, m0 + BM); half = false;
+        } else {
+            half = t == s_hpos;
+            lo = s_rs + 256 * t - ((s_hpos >= 0 && t > s_hpos) ? 256 - s_rem : 0);
+            hi = min(s_re, lo + (half ? s_rem : 256));
+            m0 = half ? lo - 128 : lo;
+            n0 = s_n0;
+        }
+    };
 
     // ---- DMA: piece = 16 rows x 64 B = 1 KiB; wave w requests pieces w, w+8 of the A tile and of the W tile: 4 per
     // K-tile (r03 measurement: with the eight requests of a K-tile on four waves those waves' issue time - ~35 visible
@@ -85,11 +141,12 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
     const char* pf_a = nullptr;
     const char* pf_w = nullptr;
     auto pf_set = [&]() {
-        int tm, tn;
-        gemm_tile_of(p, pf_tile, tm, tn);
-        if (ablate & 16) { tm &= 3; tn = 0; }              // diagnostics: every tile reads the same few (L2-resident) operand panels
-        pf_a = (const char*)p.A + (size_t)(tm * BM) * a_row + a_lane;
-        pf_w = (const char*)p.W + (size_t)(tn * BN) * w_row + w_lane;
+        int m0_, n0_, lo_, hi_;
+        bool half_;
+        tile_desc(pf_tile, m0_, n0_, lo_, hi_, half_);
+        if (ablate & 16) { m0_ &= 3 * BM; n0_ = 0; }       // diagnostics: every tile reads the same few (L2-resident) operand panels
+        pf_a = (const char*)p.A + (size_t)m0_ * a_row + a_lane;
+        pf_w = (const char*)p.W + (size_t)n0_ * w_row + w_lane;
     };
     pf_set();
     auto stage_next = [&]() {                    // no-op once the block's last K-tile has been requested
@@ -122,11 +179,12 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
     // round - a reordering of one fp32 addition per 32 products, ~1e-7 relative.
     f32x4 acc[4][8];
     auto load_resid = [&](int tl, int i) {       // m-tile i of tile tl -> acc[.][i]
-        int tm_, tn_;
-        gemm_tile_of(p, tl, tm_, tn_);
-        int m = tm_ * BM + wm * 128 + 16 * i + l15;
-        if (guard && m >= p.M) m = p.M - 1;      // rows behind M: any finite values (never stored)
-        const float* src = p.resid + (size_t)m * p.ldo + tn_ * BN + wn * 64 + 4 * g4;
+        int m0_, n0_, lo_, hi_;
+        bool half_;
+        tile_desc(tl, m0_, n0_, lo_, hi_, half_);
+        int m = m0_ + wm * 128 + 16 * i + l15;
+        if (guard && m >= p.M) m = p.M - 1;      // rows behind M: any finite values (never stored; nor are rows outside [lo, hi))
+        const float* src = p.resid + (size_t)m * p.ldo + n0_ + wn * 64 + 4 * g4;
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[j][i] = *reinterpret_cast<const f32x4*>(src + 16 * j);
     };
@@ -141,7 +199,10 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
 
     int g = 0;                                   // global index of the K-tile being multiplied
     stage_next(); stage_next(); stage_next();
-    if (issues_dma) wait_vmcnt<2 * LPT>();       // K-tile 0 (own pieces); K-tiles 1 and 2 stay in flight
+    if (issues_dma) {
+        if constexpr (PAIR) wait_vmcnt<LPT>();   // K-tiles 0 and 1 (own pieces) landed; K-tile 2 stays in flight
+        else wait_vmcnt<2 * LPT>();              // K-tile 0 (own pieces); K-tiles 1 and 2 stay in flight
+    }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     WideFrags P, Q;
@@ -178,10 +239,49 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
         ++g;                                                                                                           \
     }
 
+    // PAIR, first K-tile of a pair: no wait for DMA, no barrier
+#define MOCR_PERS_KTILE_A(CUR, NXT)                                                                                    \
+    {                                                                                                                  \
+        const unsigned so = (unsigned)((g & 3) * STAGE), sn = (unsigned)(((g + 1) & 3) * STAGE);                        \
+        MOCR_W2_READ_TAIL(CUR, offA + so);                                                                             \
+        stage_next();                                     /* K-tile g + 3 into the slot of K-tile g - 1 */              \
+        asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(CUR.fb[0]), "+v"(CUR.fb[1]), "+v"(CUR.fb[2]), "+v"(CUR.fb[3]),      \
+                     "+v"(CUR.fa[0]), "+v"(CUR.fa[1]));                                                                \
+        MOCR_W2_GROUP(CUR, 0);                                                                                         \
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(CUR.fa[2]), "+v"(CUR.fa[3]));                                       \
+        MOCR_W2_GROUP(CUR, 1);                                                                                         \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(CUR.fa[4]), "+v"(CUR.fa[5]), "+v"(CUR.fa[6]), "+v"(CUR.fa[7]));     \
+        MOCR_W2_READ_HEAD(NXT, offA + sn, offB + sn);     /* K-tile g + 1: proved landed by the last barrier */         \
+        MOCR_W2_GROUP(CUR, 2);                                                                                         \
+        MOCR_W2_GROUP(CUR, 3);                                                                                         \
+        ++g;                                                                                                           \
+    }
+    // PAIR, second K-tile of a pair: everything requested so far has landed (K-tiles g + 1, g + 2), barrier, refill
+#define MOCR_PERS_KTILE_B(CUR, NXT)                                                                                    \
+    {                                                                                                                  \
+        const unsigned so = (unsigned)((g & 3) * STAGE), sn = (unsigned)(((g + 1) & 3) * STAGE);                        \
+        MOCR_W2_READ_TAIL(CUR, offA + so);                                                                             \
+        asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(CUR.fb[0]), "+v"(CUR.fb[1]), "+v"(CUR.fb[2]), "+v"(CUR.fb[3]),      \
+                     "+v"(CUR.fa[0]), "+v"(CUR.fa[1]));                                                                \
+        MOCR_W2_GROUP(CUR, 0);                                                                                         \
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(CUR.fa[2]), "+v"(CUR.fa[3]));                                       \
+        MOCR_W2_GROUP(CUR, 1);                                                                                         \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(CUR.fa[4]), "+v"(CUR.fa[5]), "+v"(CUR.fa[6]), "+v"(CUR.fa[7]));     \
+        if (issues_dma) wait_vmcnt<0>();                  /* a DMA wave's queue holds nothing but these requests */     \
+        __builtin_amdgcn_s_barrier();                                                                                  \
+        asm volatile("" ::: "memory");                                                                                 \
+        stage_next();                                     /* K-tile g + 3 into the slot of K-tile g - 1 */              \
+        MOCR_W2_READ_HEAD(NXT, offA + sn, offB + sn);                                                                  \
+        MOCR_W2_GROUP(CUR, 2);                                                                                         \
+        MOCR_W2_GROUP(CUR, 3);                                                                                         \
+        ++g;                                                                                                           \
+    }
+
     for (; tile < tile_end; tile += tstride) {
-        int tm, tn;
-        gemm_tile_of(p, tile, tm, tn);
-        const int m0 = tm * BM, n0 = tn * BN;
+        int m0, n0, row_lo, row_hi;
+        bool half;
+        tile_desc(tile, m0, n0, row_lo, row_hi, half);
+        const unsigned own_lo = (unsigned)(row_lo - m0), own_n = (unsigned)(row_hi - row_lo);      // the tile's own rows, window-relative
         // bias of this lane's 16 columns: requested here, used in the epilogue (a load in front of the K loop instead of
         // a round trip in the epilogue)
         // (EPI_BIAS_RESID: every register counts there - the bias is added by the store waves instead, to whole rows: a
@@ -198,9 +298,31 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
                 bias[j][0] = bv.x; bias[j][1] = bv.y; bias[j][2] = bv.z; bias[j][3] = bv.w;
             }
         }
-        for (int t = 0; t < nt; t += 2) {
-            MOCR_PERS_KTILE(P, Q)
-            MOCR_PERS_KTILE(Q, P)
+        if (STRIP && half && wm == 0) {
+            // half tile: rows 0..127 of the window belong to another tile - these waves (0-3: the DMA waves) only keep the
+            // ring and the barriers going, in the order of the two macros above
+            for (int t = 0; t < nt; t += 2) {
+                stage_next();
+                ++g;
+                if (issues_dma) wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                stage_next();
+                ++g;
+            }
+            // the first six fragments of the next tile's first K-tile (landed: the last barrier), as the other waves' last
+            // K-tile requested them
+            MOCR_W2_READ_HEAD(P, offA + (unsigned)((g & 3) * STAGE), offB + (unsigned)((g & 3) * STAGE));
+        } else if constexpr (PAIR) {
+            for (int t = 0; t < nt; t += 2) {
+                MOCR_PERS_KTILE_A(P, Q)
+                MOCR_PERS_KTILE_B(Q, P)
+            }
+        } else {
+            for (int t = 0; t < nt; t += 2) {
+                MOCR_PERS_KTILE(P, Q)
+                MOCR_PERS_KTILE(Q, P)
+            }
         }
         // ------------------------------------------------------------------------------------------ epilogue of `tile`
         // LDS free right now: the slot of the K-tile just multiplied, (g - 1) & 3 (every wave passed that K-tile's barrier
@@ -328,7 +450,8 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
                         for (int it = 0; it < 8; ++it) {
                             const int sr = 16 * sw + 8 * hf + it;
                             const int row = (sr >> 5) * 128 + 32 * q + (sr & 31);
-                            if ((!guard || m0 + row < p.M) && !(ablate & 8))
+                            const bool mine = STRIP ? (unsigned)row - own_lo < own_n : (!guard || m0 + row < p.M);
+                            if (mine && !(ablate & 8))
                                 *reinterpret_cast<float4*>(obase + (size_t)row * ldo) =
                                     make_float4(v[it].x + bias_row.x, v[it].y + bias_row.y, v[it].z + bias_row.z, v[it].w + bias_row.w);
                         }
@@ -341,6 +464,8 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
         }
     }
 #undef MOCR_PERS_KTILE
+#undef MOCR_PERS_KTILE_A
+#undef MOCR_PERS_KTILE_B
     // the reads requested behind the last barrier: landed before their registers are used for anything else
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(P.fb[0]), "+v"(P.fb[1]), "+v"(P.fb[2]), "+v"(P.fb[3]), "+v"(P.fa[0]), "+v"(P.fa[1]));
 }

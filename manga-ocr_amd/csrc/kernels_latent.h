@@ -21,6 +21,7 @@
 // ds_read_b64_tr_b16 (2-way conflicts, irrelevant next to the 48 KiB/tile HBM stream).
 #pragma once
 #include "common.h"
+#include "kernels_attn.h"
 
 #define LAT_D 768
 #define LAT_TK 32
@@ -68,10 +69,7 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
-// LDS byte address (what ds_* instructions take) of a pointer into the dynamic LDS array
-__device__ __forceinline__ unsigned lds_addr(const void* p) {
-    return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const char*)p;
-}
+// (lds_addr: kernels_attn.h)
 // Six transposed 4x16 block reads + their wait in ONE asm statement (the compiler neither counts
 // nor pads inline-asm LDS reads: cdna_hip_programming.md §5.7 form (i)).  hipcc puts a
 // s_waitcnt vmcnt(0) in front of the ds_read_tr builtin while LDS-DMA is in flight (it cannot

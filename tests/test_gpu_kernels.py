@@ -106,7 +106,7 @@ def test_gemm_256x128_three_stage_ring(M, N, K, epi, tile):
 
 @pytest.mark.parametrize("epi", [EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID])
 @pytest.mark.parametrize("tile,M,N,K", [(4096, 8900, 2304, 768), (4097, 2500, 768, 3072), (4097, 1300, 3072, 128), (4096, 33000, 768, 768)] +
-                         ([(4098, 8900, 2304, 768)] if LAB else []))
+                         ([(4098, 8900, 2304, 768), (4101, 8900, 2304, 768), (4102, 2500, 768, 3072), (4102, 1300, 3072, 128)] if LAB else []))
 def test_gemm_persistent_blocks_walk_several_tiles(epi, tile, M, N, K):
     """gemm_pers_kernel (tile code 4096; 4097 = the same kernel on 8 blocks): a block multiplies a SEQUENCE of 256 x 256
     tiles - the LDS ring runs across tile boundaries, the epilogue is staged through the slot the last K-tile left, and
@@ -184,11 +184,15 @@ def test_layernorm(dtype):
     assert err <= tol
 
 
-@pytest.mark.parametrize("dtype,impl", [("fp32", 0), ("bf16", 0), ("bf16", 1)])
-def test_encoder_attention(dtype, impl):
+@pytest.mark.parametrize("dtype,impl,n", [("fp32", 0, 3), ("bf16", 0, 3), ("bf16", 1, 3), ("bf16", 1, 1), ("bf16", 1, 30), ("bf16", 1, 70)] +
+                         ([("bf16", 2, 3)] if LAB else []))
+def test_encoder_attention(dtype, impl, n):
+    """impl 0: the VALU kernel (fp32 parity mode); 1: the MFMA kernel of the bf16 engine (K / V by LDS-DMA, V read
+    column-wise with ds_read_b64_tr_b16) - 1 crop (four blocks share a head's 13 query units), 3 / 30 (two), 70 (one block
+    per head, three blocks per CU); 2: the r02 kernel (experiments build)."""
     eng = engine(dtype)
-    rs = np.random.RandomState(11 + impl)
-    n, S, H, dh = 3, 197, 12, 64
+    rs = np.random.RandomState(11 + impl + n)
+    S, H, dh = 197, 12, 64
     qkv = (rs.standard_normal((n * S, 3 * H * dh)) * 1.5).astype(np.float32)
     if dtype == "bf16":
         qkv = bf16_round(qkv)
