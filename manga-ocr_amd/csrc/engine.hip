@@ -491,7 +491,7 @@ void gemm(mocr_engine* e, const char* name, const void* A, int lda, const void* 
     // 4099 / 4100: the strip schedule forced (whole grid / 8 blocks) - test hooks like 4097
     if (tile == 4096 || tile == 4097 || tile == 4099 || tile == 4100) {
         const int blocks = (tile == 4097 || tile == 4100) ? 8 : 0;     // 4097: test hook, 8 blocks walk all the tiles
-        static const int strip_env = env_int("MOCR_GEMM_STRIP", -1);
+        static const int strip_env = env_int("MOCR_GEMM_STRIP", 0);      // -1 once measured
         const int strip = tile >= 4099 ? 1 : tile == 4097 ? 0 : strip_env;
         if (epi == EPI_BIAS_RESID) launch_gemm_pers<true, true>(e, p, epi, blocks, strip);
         else launch_gemm_pers<true, false>(e, p, epi, blocks);
