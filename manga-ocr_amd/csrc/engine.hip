@@ -67,6 +67,10 @@ static inline uint16_t host_f2bf(float f) {
 struct EncLayerW {
     void *wqkv, *wo, *w1, *w2;
     float *bqkv, *bo, *b1, *b2, *ln1g, *ln1b, *ln2g, *ln2b;
+    // bf16 engines, LayerNorm folded into the GEMM behind it (gemm_pers_kernel LNF): W o gamma, its column sums (of the
+    // bf16-rounded values), b + W beta
+    void *wqkv_f = nullptr, *w1_f = nullptr;
+    float *sqkv = nullptr, *s1 = nullptr, *bqkv_f = nullptr, *b1_f = nullptr;
 };
 struct DecLayerW {
     void *wqkv, *wo, *wqc, *woc, *w1, *w2;
@@ -105,6 +109,7 @@ struct LaneCtx {
     uint8_t *d_in = nullptr, *d_rgb = nullptr;
     float* X = nullptr;
     void *Xn = nullptr, *QKV = nullptr, *CTX = nullptr, *Hb = nullptr, *ENC = nullptr, *CKV = nullptr;
+    float* ln_part = nullptr;                  // [Mp][4][2] row statistics partials of X (LayerNorm folded into the encoder GEMMs)
     void *kcache = nullptr, *vcache = nullptr;     // [dec_layers][Bp][H][max_len][64]
     float* slabs = nullptr; long long slab_cap = 0; // floats
     float* cand_val = nullptr; int* cand_idx = nullptr;   // [Bp][vocab/64] per-tile argmax candidates of the LM head
@@ -396,7 +401,7 @@ static bool pers_strip_wins(int M, int ntn, int grid) {
     return strip_cost <= 0.95 * per_block;
 }
 
-template <int EPI, bool SPLIT_DMA, bool PAIR = false, bool STRIP = false>
+template <int EPI, bool SPLIT_DMA, bool PAIR = false, bool STRIP = false, bool LNF = false>
 void launch_gemm_pers_t(mocr_engine* e, const GemmParams& p0, int blocks) {
     GemmParams p = p0;
     p.ntn = p.N / 256;
@@ -406,20 +411,35 @@ void launch_gemm_pers_t(mocr_engine* e, const GemmParams& p0, int blocks) {
     grid = std::max(8, grid / 8 * 8);
     static const int stagger_env = env_int("MOCR_GEMM_STAGGER", 0);
     p.stagger = stagger_env;
-    hipLaunchKernelGGL((gemm_pers_kernel<EPI, SPLIT_DMA, PAIR, STRIP>), dim3(grid), dim3(512), PERS_LDS, e->stream, p);
+    hipLaunchKernelGGL((gemm_pers_kernel<EPI, SPLIT_DMA, PAIR, STRIP, LNF>), dim3(grid), dim3(512), PERS_LDS, e->stream, p);
     HIPCHECK(hipGetLastError());
 }
 
-// strip: 0 tile list, 1 strips, -1 whichever walks fewer rounds (EPI_BIAS_RESID only; the other epilogues keep the list)
+// strip: 0 tile list, 1 strips, -1 whichever walks fewer rounds (EPI_BIAS_RESID only; the other epilogues keep the list).
+// p.ln_part set: the LayerNorm-folding forms of the kernel (kernels_gemm_pers.h, LNF).
 template <bool SPLIT_DMA, bool PAIR = false>
 void launch_gemm_pers(mocr_engine* e, const GemmParams& p, int epi, int blocks, int strip = 0) {
     if (p.k_per_split % 64 || p.k_per_split < 128) throw ArgError{"persistent gemm: K must be a multiple of 64, >= 128", MOCR_ERR_ARG};
-    if constexpr (SPLIT_DMA && PAIR) {
+    const bool lnf = p.ln_part != nullptr;
+    if (lnf && !(SPLIT_DMA && (epi == EPI_BIAS_RESID ? (PAIR && p.N <= 1024 && p.xb) : (!PAIR && p.csum))))
+        throw ArgError{"persistent gemm: LayerNorm folding needs the product kernel forms and their operands", MOCR_ERR_ARG};
+    if constexpr (SPLIT_DMA) {
         if (epi == EPI_BIAS_RESID && strip) {
             const int ntn = p.N / 256, ntiles = ((p.M + 255) / 256) * ntn;
             const int grid = std::max(8, std::min(blocks > 0 ? blocks : e->num_cus, (ntiles + 7) / 8 * 8) / 8 * 8);
             if (strip > 0 ? pers_strip_rows(p.M, ntn, grid) > 0 : pers_strip_wins(p.M, ntn, grid)) {
-                launch_gemm_pers_t<EPI_BIAS_RESID, true, true, true>(e, p, blocks);
+                if constexpr (PAIR) {
+                    if (lnf) { launch_gemm_pers_t<EPI_BIAS_RESID, true, true, true, true>(e, p, blocks); return; }
+                }
+                launch_gemm_pers_t<EPI_BIAS_RESID, true, PAIR, true>(e, p, blocks);
+                return;
+            }
+        }
+        if (lnf) {
+            if constexpr (PAIR) { launch_gemm_pers_t<EPI_BIAS_RESID, true, true, false, true>(e, p, blocks); return; }
+            else {
+                if (epi == EPI_BIAS) launch_gemm_pers_t<EPI_BIAS, true, false, false, true>(e, p, blocks);
+                else launch_gemm_pers_t<EPI_BIAS_GELU, true, false, false, true>(e, p, blocks);
                 return;
             }
         }
@@ -459,11 +479,15 @@ void launch_gemm_wide(mocr_engine* e, const GemmParams& p, int epi) {
 // 4097: the same on 8 blocks, a test hook); experiments build only: 256, 512, 1024, 2048, 4098 (kernels_gemm_lab.h).
 // split > 1 only with EPI_SLAB.
 struct HeadBatch { int heads = 1; long long a_yoff = 0, w_yoff = 0, o_yoff = 0, b_yoff = 0; int ldw = 0; };
+// LayerNorm folded into the persistent encoder GEMMs (tile code 4096; kernels_gemm_pers.h LNF).  EPI_BIAS_RESID: `part` and
+// `xb` are written; EPI_BIAS / EPI_BIAS_GELU: `part` and `csum` are read (W and bias are the folded ones).
+struct LnFold { float* part = nullptr; const float* csum = nullptr; void* xb = nullptr; };
 
 template <typename T>
 void gemm(mocr_engine* e, const char* name, const void* A, int lda, const void* W, const float* bias, void* out, int ldo,
           const float* resid, int M, int N, int K, int epi, int tile, int split, long long slab_stride = 0,
-          const float* pos = nullptr, int patches = 0, const HeadBatch* hb = nullptr, int group_n = 0, int* cand_idx = nullptr) {
+          const float* pos = nullptr, int patches = 0, const HeadBatch* hb = nullptr, int group_n = 0, int* cand_idx = nullptr,
+          const LnFold* lnf = nullptr) {
     const int kt = 128 / (int)sizeof(T);
     if (N % (tile >= 1024 ? 256 : tile >= 256 ? 128 : std::max(tile, 1)) || K % (kt * split) || (split > 1 && epi != EPI_SLAB) ||
         (tile >= 256 && (sizeof(T) != 2 || split != 1)))
@@ -478,20 +502,24 @@ void gemm(mocr_engine* e, const char* name, const void* A, int lda, const void* 
         if (hb->ldw) p.ldw = hb->ldw;
     }
     p.k_per_split = K / split; p.slab_stride = slab_stride; p.patches = patches;
+    if (lnf) {
+        if (tile < 4096 || tile > 4100 || sizeof(T) != 2) throw ArgError{"LayerNorm folding: persistent bf16 GEMMs only", MOCR_ERR_ARG};
+        p.ln_part = lnf->part; p.csum = lnf->csum; p.xb = lnf->xb; p.ln_eps = e->cfg.ln_eps;
+    }
     static const int ablate = env_int("MOCR_GEMM_ABLATE", 0);
     p.ablate = ablate;
     static const int group_env = env_int("MOCR_GEMM_GROUPN", -1);
     p.group_n = group_env >= 0 ? group_env : group_n;
     const double out_b = (epi == EPI_BIAS || epi == EPI_BIAS_GELU) ? sizeof(T) : 4.0;
     const double bytes = ((double)M * K + (double)N * K) * sizeof(T) + (double)M * N * out_b * (epi == EPI_SLAB ? split : 1) +
-                         (epi == EPI_BIAS_RESID ? (double)M * N * 4 : 0);
+                         (epi == EPI_BIAS_RESID ? (double)M * N * 4 : 0) + (lnf && epi == EPI_BIAS_RESID ? (double)M * N * 2 : 0);
     ProfScope ps(e, name, 2.0 * M * N * K * ybatch, bytes * ybatch);
     // one barrier per two K-tiles for the fp32-residual GEMMs (r03, M = 50,432: O-proj 137 -> 129 us, FC2 305 -> 302; the
     // bf16-output GEMMs lose with it: QKV 175 -> 208 us)
     // 4099 / 4100: the strip schedule forced (whole grid / 8 blocks) - test hooks like 4097
     if (tile == 4096 || tile == 4097 || tile == 4099 || tile == 4100) {
         const int blocks = (tile == 4097 || tile == 4100) ? 8 : 0;     // 4097: test hook, 8 blocks walk all the tiles
-        static const int strip_env = env_int("MOCR_GEMM_STRIP", 0);      // -1 once measured
+        static const int strip_env = env_int("MOCR_GEMM_STRIP", -1);     // -1: strips where they walk fewer rounds (r03, M = 50,432: O-proj 133 -> 113 us, FC2 303 -> 275)
         const int strip = tile >= 4099 ? 1 : tile == 4097 ? 0 : strip_env;
         if (epi == EPI_BIAS_RESID) launch_gemm_pers<true, true>(e, p, epi, blocks, strip);
         else launch_gemm_pers<true, false>(e, p, epi, blocks);
@@ -500,6 +528,8 @@ void gemm(mocr_engine* e, const char* name, const void* A, int lda, const void* 
     else if (tile == 4098) launch_gemm_pers<false>(e, p, epi, 0);   // experiment: every wave requests LDS-DMA
     else if (tile == 4101) launch_gemm_pers<true, true>(e, p, epi, 0);    // experiment: one barrier per two K-tiles
     else if (tile == 4102) launch_gemm_pers<true, true>(e, p, epi, 8);
+    else if (tile == 4103) launch_gemm_pers<true, false>(e, p, epi, 0, 1);      // experiment: strips on the one-barrier-per-K-tile loop
+    else if (tile == 4104) launch_gemm_pers<true, false>(e, p, epi, 8, 1);
     else if (tile == 2048) launch_gemm_wide2(e, p, epi);
     else if (tile == 1024) launch_gemm_wide<4>(e, p, epi);
     else if (tile == 512) launch_gemm_wide<2>(e, p, epi);
@@ -1087,7 +1117,12 @@ template <typename T> void init_kernel_attrs() {
     set_max_lds(gemm_pers_kernel<EPI_BIAS_RESID, true>, PERS_LDS);
     set_max_lds(gemm_pers_kernel<EPI_BIAS_RESID, true, true>, PERS_LDS);
     set_max_lds(gemm_pers_kernel<EPI_BIAS_RESID, true, true, true>, PERS_LDS);
+    set_max_lds(gemm_pers_kernel<EPI_BIAS_RESID, true, true, true, true>, PERS_LDS);
+    set_max_lds(gemm_pers_kernel<EPI_BIAS_RESID, true, true, false, true>, PERS_LDS);
+    set_max_lds(gemm_pers_kernel<EPI_BIAS, true, false, false, true>, PERS_LDS);
+    set_max_lds(gemm_pers_kernel<EPI_BIAS_GELU, true, false, false, true>, PERS_LDS);
 #ifdef MOCR_EXPERIMENTS
+    set_max_lds(gemm_pers_kernel<EPI_BIAS_RESID, true, false, true>, PERS_LDS);
     set_max_lds(gemm_pers_kernel<EPI_BIAS, true, true>, PERS_LDS);
     set_max_lds(gemm_pers_kernel<EPI_BIAS_GELU, true, true>, PERS_LDS);
     set_max_lds(gemm_pers_kernel<EPI_BIAS, false>, PERS_LDS);
@@ -1523,6 +1558,10 @@ void allocate_lane(mocr_engine* e, int lane_id) {
     e->d_rgb = e->dalloc<uint8_t>((size_t)c.max_batch * c.image_size * c.image_size * 3);
     e->X = e->dalloc<float>(Mp * D);
     e->Xn = e->dalloc<char>(Mp * D * esz);
+    if (c.dtype == MOCR_BF16) {
+        e->ln_part = e->dalloc<float>(Mp * 8);
+        HIPCHECK(hipMemset(e->ln_part, 0, Mp * 8 * sizeof(float)));      // (partial 3 stays zero: N = 768 has three column slices)
+    }
     e->QKV = e->dalloc<char>(Mp * 3 * D * esz);
     e->CTX = e->dalloc<char>(Mp * D * esz);
     e->Hb = e->dalloc<char>(Mp * (size_t)e->F * esz);

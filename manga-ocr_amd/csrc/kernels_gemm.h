@@ -57,6 +57,12 @@ struct GemmParams {
     int ntm;               // tiles along M
     int stagger;           // wide2: the first-round blocks start up to this many x 1024 cycles late (0 = together)
     int first_round;       // blocks that start at launch (one per CU)
+    // LayerNorm folded into the encoder's persistent GEMMs (gemm_pers_kernel LNF, kernels_gemm_pers.h):
+    float* ln_part;        // [M][4][2] per-row partial (sum, sum of squares) over each 256-column slice of the fp32 rows:
+                           // written by the fp32-residual GEMM (slice = its N-tile), read by the GEMM that multiplies the rows
+    const float* csum;     // [N] column sums of the folded weight W o gamma (as rounded to bf16)
+    void* xb;              // fp32-residual GEMM: bf16 copy of the output rows, [M][ldo]
+    float ln_eps;
 };
 
 // Linear tile id -> (tm, tn).  Tiles are ordered column-group by column-group: inside a group of
@@ -407,6 +413,12 @@ struct WideFrags { bf16x8 fb[4]; bf16x8 fa[8]; };
     asm volatile("ds_read_b128 %0, %6 offset:2048\n\tds_read_b128 %1, %6 offset:3072\n\tds_read_b128 %2, %6 offset:4096\n\t" \
                  "ds_read_b128 %3, %6 offset:5120\n\tds_read_b128 %4, %6 offset:6144\n\tds_read_b128 %5, %6 offset:7168" \
                  : "=&v"(F.fa[2]), "=&v"(F.fa[3]), "=&v"(F.fa[4]), "=&v"(F.fa[5]), "=&v"(F.fa[6]), "=&v"(F.fa[7])       \
+                 : "v"(aA)                                                                                               \
+                 : "memory")
+// a half tile's wave (64 x 64, gemm_pers_kernel STRIP): A fragments 2 and 3 only
+#define MOCR_W2_READ_TAIL2(F, aA)                                                                                       \
+    asm volatile("ds_read_b128 %0, %2 offset:2048\n\tds_read_b128 %1, %2 offset:3072"                                   \
+                 : "=&v"(F.fa[2]), "=&v"(F.fa[3])                                                                        \
                  : "v"(aA)                                                                                               \
                  : "memory")
 #define MOCR_W2_GROUP(F, g)                                                                                             \

@@ -36,9 +36,17 @@ constexpr int PERS_LDS = 160 * 1024;      // four 32 KiB ring slots + 32 KiB tha
 // three.
 // STRIP (with PAIR, EPI_BIAS_RESID: the N = 768 GEMMs): the block owns a STRIP of rows of ONE 256-column slice instead of
 // whole 256-row tiles of a shared list - see the schedule below.
-template <int EPI, bool SPLIT_DMA, bool PAIR = false, bool STRIP = false>
+// LNF: the encoder's LayerNorms folded into the GEMMs on both sides of them (r03; the LayerNorm launches were 7.5 % of the
+// encoder at batch 256 for no FLOP).  LN(x) W^T + b = rstd (x (W o gamma)^T - mean colsum(W o gamma)) + (b + W beta):
+//   * EPI_BIAS_RESID (the GEMM that WRITES the residual stream x): its store waves hold whole 256-column row segments of
+//     the new x - they also write them as bf16 (p.xb: the A operand of the next GEMM, x itself, not LN(x)) and their
+//     (sum, sum of squares) to p.ln_part[row][N-tile];
+//   * EPI_BIAS / EPI_BIAS_GELU (the GEMM that multiplies LN(x)): A = bf16 x, W = bf16(W o gamma), p.bias = b + W beta,
+//     p.csum = column sums of the folded weight; the epilogue finishes each row's statistics from the partials (one-pass
+//     variance in fp32: fine while mean^2 is not orders of magnitude above the variance) and applies the identity above.
+template <int EPI, bool SPLIT_DMA, bool PAIR = false, bool STRIP = false, bool LNF = false>
 __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
-    static_assert(!STRIP || (PAIR && SPLIT_DMA), "the strip schedule's half tiles rely on the PAIR loop's count-free waits");
+    static_assert(!STRIP || SPLIT_DMA, "the strip schedule is built on the split-role kernel");
     constexpr int BM = 256, BN = 256, WN = 4;
     constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64, STAGE = A_BYTES + B_BYTES;   // 32 KiB per 32-deep K-tile
     constexpr int RING = 4 * STAGE;                                                  // 128 KiB; + 32 KiB spare = 160 KiB
@@ -63,11 +71,10 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
     // STRIP: at M = 50,432 the N = 768 GEMMs have 591 tiles for 256 CUs - three rounds for 2.31 rounds of work, and every CU
     // reaches its HBM-bound fp32 epilogue (256 KiB read + 256 KiB written) in the same microseconds.  Instead the rows are
     // cut into `nstrips` strips of whole 16-row units (85 strips of 592 / 608 rows there), a block owns one strip of one
-    // 256-column slice and walks it as 256-row tiles plus ONE half tile for a remainder of up to 128 rows: only the waves
-    // that own the tile's rows 128..255 (waves 4-7) multiply it - one wave per SIMD, half the matrix work of a tile - while
-    // waves 0-3 keep requesting the LDS-DMA and meeting the barriers.  The half tile comes first, in the middle or last by
-    // strip number, so that the blocks of the chip reach their epilogues at different times.  The `ntn` blocks of a strip
-    // are neighbours in one XCD's block order (they read the same A row-panel at the same time).
+    // 256-column slice and walks it as 256-row tiles plus ONE half tile (128 x 256: a wave owns 64 x 64, half the MFMAs, A
+    // fragments and A pieces of a K-tile) for a remainder of up to 128 rows.  The half tile comes first, in the middle or
+    // last by strip number, so that the blocks of the chip reach their epilogues at different times.  The `ntn` blocks of
+    // a strip are neighbours in one XCD's block order (they read the same A row-panel at the same time).
     const int ntiles = p.ntm * p.ntn;
     int tile, tile_end, tstride;
     int s_rs = 0, s_re = 0, s_n0 = 0, s_rem = 0, s_hpos = -1;      // STRIP: rows [s_rs, s_re), column, remainder rows, half tile's position
@@ -96,7 +103,6 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
                 if (s_rem && s_rem <= 128) {
                     const int v = strip % 3;
                     s_hpos = v == 0 ? tile_end - 1 : v == 1 ? 0 : tile_end >> 1;
-                    if (s_hpos == 0 && s_rs < 128) s_hpos = tile_end > 1 ? tile_end - 1 : -1;      // a half tile starts 128 rows above its rows
                 }
                 s_n0 = col * BN;
             }
@@ -123,7 +129,9 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
             half = t == s_hpos;
             lo = s_rs + 256 * t - ((s_hpos >= 0 && t > s_hpos) ? 256 - s_rem : 0);
             hi = min(s_re, lo + (half ? s_rem : 256));
-            m0 = half ? lo - 128 : lo;
+            // the 256-row (half tile: 128-row) window ends with the tile's last row where the tile is short: no row behind
+            // the strip is ever read (rows of the window above `lo` are another tile's: multiplied, never stored)
+            m0 = max(0, min(lo, hi - (half ? 128 : 256)));
             n0 = s_n0;
         }
     };
@@ -140,10 +148,12 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
     int pf_g = 0;
     const char* pf_a = nullptr;
     const char* pf_w = nullptr;
+    bool pf_half = false;                        // STRIP: the tile being requested is a half tile (A rows 128..255 are not requested)
     auto pf_set = [&]() {
         int m0_, n0_, lo_, hi_;
         bool half_;
         tile_desc(pf_tile, m0_, n0_, lo_, hi_, half_);
+        pf_half = half_;
         if (ablate & 16) { m0_ &= 3 * BM; n0_ = 0; }       // diagnostics: every tile reads the same few (L2-resident) operand panels
         pf_a = (const char*)p.A + (size_t)m0_ * a_row + a_lane;
         pf_w = (const char*)p.W + (size_t)n0_ * w_row + w_lane;
@@ -157,7 +167,13 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
         const char* ga = pf_a + (size_t)pf_kt * 64;
         const char* gw = pf_w + (size_t)pf_kt * 64;
 #pragma unroll
-        for (int i = 0; i < NPIECE; ++i) glds16(ga + (size_t)(16 * PSTEP * i) * a_row, sa + i * PSTEP * 1024);
+        for (int i = 0; i < NPIECE; ++i) {
+            // a half tile has no A rows 128..255: not requested (PAIR) / rows 0..127 requested again (the counted waits of
+            // the !PAIR loop need every K-tile's requests alike) - never a row behind the tile's last
+            const bool upper = STRIP && pf_half && i >= NPIECE / 2;
+            if (PAIR && upper) continue;
+            glds16(ga + (size_t)(16 * PSTEP * (upper ? i - NPIECE / 2 : i)) * a_row, sa + i * PSTEP * 1024);
+        }
 #pragma unroll
         for (int i = 0; i < NPIECE; ++i) glds16(gw + (size_t)(16 * PSTEP * i) * w_row, sa + A_BYTES + i * PSTEP * 1024);
         ++pf_g;
@@ -182,7 +198,8 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
         int m0_, n0_, lo_, hi_;
         bool half_;
         tile_desc(tl, m0_, n0_, lo_, hi_, half_);
-        int m = m0_ + wm * 128 + 16 * i + l15;
+        if (STRIP && half_ && i >= 4) return;    // a half tile's wave owns m-tiles 0..3: rows 64 wm + 16 i
+        int m = m0_ + wm * (STRIP && half_ ? 64 : 128) + 16 * i + l15;
         if (guard && m >= p.M) m = p.M - 1;      // rows behind M: any finite values (never stored; nor are rows outside [lo, hi))
         const float* src = p.resid + (size_t)m * p.ldo + n0_ + wn * 64 + 4 * g4;
 #pragma unroll
@@ -200,19 +217,27 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
     int g = 0;                                   // global index of the K-tile being multiplied
     stage_next(); stage_next(); stage_next();
     if (issues_dma) {
-        if constexpr (PAIR) wait_vmcnt<LPT>();   // K-tiles 0 and 1 (own pieces) landed; K-tile 2 stays in flight
-        else wait_vmcnt<2 * LPT>();              // K-tile 0 (own pieces); K-tiles 1 and 2 stay in flight
+        if constexpr (STRIP && PAIR) wait_vmcnt<0>(); // (a half tile's K-tiles have fewer requests: no count)
+        else if constexpr (PAIR) wait_vmcnt<LPT>();   // K-tiles 0 and 1 (own pieces) landed; K-tile 2 stays in flight
+        else wait_vmcnt<2 * LPT>();                   // K-tile 0 (own pieces); K-tiles 1 and 2 stay in flight
     }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    // STRIP: a half tile's wave reads its A fragments from rows 64 wm .. of the K-tile instead of 128 wm ..: `hadj` bytes
+    // lower (hadj: the tile being multiplied; hadj_nx: the block's next tile)
+    const unsigned hadj_unit = STRIP ? (unsigned)(wm * 64 * 64) : 0u;
+    unsigned hadj = 0, hadj_nx = 0;
+    if constexpr (STRIP) {
+        if (tile == s_hpos) hadj = hadj_unit;
+    }
     WideFrags P, Q;
-    MOCR_W2_READ_HEAD(P, offA, offB);
+    MOCR_W2_READ_HEAD(P, offA - hadj, offB);
 
     // one K-tile: CUR holds its first six fragments (requested during the previous K-tile), NXT receives those of the next
 #define MOCR_PERS_KTILE(CUR, NXT)                                                                                      \
     {                                                                                                                  \
         const unsigned so = (unsigned)((g & 3) * STAGE), sn = (unsigned)(((g + 1) & 3) * STAGE);                        \
-        MOCR_W2_READ_TAIL(CUR, offA + so);                                                                             \
+        MOCR_W2_READ_TAIL(CUR, offA + so - hadj);                                                                           \
         stage_next();                                     /* K-tile g + 3 into the slot of K-tile g - 1 */              \
         asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(CUR.fb[0]), "+v"(CUR.fb[1]), "+v"(CUR.fb[2]), "+v"(CUR.fb[3]),      \
                      "+v"(CUR.fa[0]), "+v"(CUR.fa[1]));                                                                \
@@ -233,9 +258,11 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
         }                                                                                                              \
         __builtin_amdgcn_s_barrier();                                                                                  \
         asm volatile("" ::: "memory");                                                                                 \
-        MOCR_W2_READ_HEAD(NXT, offA + sn, offB + sn);                                                                  \
-        MOCR_W2_GROUP(CUR, 2);                                                                                         \
-        MOCR_W2_GROUP(CUR, 3);                                                                                         \
+        MOCR_W2_READ_HEAD(NXT, offA + sn - hadj_k, offB + sn);      /* hadj_k: of the tile K-tile g + 1 belongs to */   \
+        if (!(STRIP && half)) {                           /* a half tile's wave owns 64 rows: m-tiles 0..3 */           \
+            MOCR_W2_GROUP(CUR, 2);                                                                                     \
+            MOCR_W2_GROUP(CUR, 3);                                                                                     \
+        }                                                                                                              \
         ++g;                                                                                                           \
     }
 
@@ -243,7 +270,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
 #define MOCR_PERS_KTILE_A(CUR, NXT)                                                                                    \
     {                                                                                                                  \
         const unsigned so = (unsigned)((g & 3) * STAGE), sn = (unsigned)(((g + 1) & 3) * STAGE);                        \
-        MOCR_W2_READ_TAIL(CUR, offA + so);                                                                             \
+        MOCR_W2_READ_TAIL(CUR, offA + so - hadj);                                                                             \
         stage_next();                                     /* K-tile g + 3 into the slot of K-tile g - 1 */              \
         asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(CUR.fb[0]), "+v"(CUR.fb[1]), "+v"(CUR.fb[2]), "+v"(CUR.fb[3]),      \
                      "+v"(CUR.fa[0]), "+v"(CUR.fa[1]));                                                                \
@@ -251,16 +278,18 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
         asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(CUR.fa[2]), "+v"(CUR.fa[3]));                                       \
         MOCR_W2_GROUP(CUR, 1);                                                                                         \
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(CUR.fa[4]), "+v"(CUR.fa[5]), "+v"(CUR.fa[6]), "+v"(CUR.fa[7]));     \
-        MOCR_W2_READ_HEAD(NXT, offA + sn, offB + sn);     /* K-tile g + 1: proved landed by the last barrier */         \
-        MOCR_W2_GROUP(CUR, 2);                                                                                         \
-        MOCR_W2_GROUP(CUR, 3);                                                                                         \
+        MOCR_W2_READ_HEAD(NXT, offA + sn - hadj, offB + sn);     /* K-tile g + 1 (same tile): proved landed by the last barrier */ \
+        if (!(STRIP && half)) {                           /* a half tile's wave owns 64 rows: m-tiles 0..3 */           \
+            MOCR_W2_GROUP(CUR, 2);                                                                                     \
+            MOCR_W2_GROUP(CUR, 3);                                                                                     \
+        }                                                                                                              \
         ++g;                                                                                                           \
     }
     // PAIR, second K-tile of a pair: everything requested so far has landed (K-tiles g + 1, g + 2), barrier, refill
 #define MOCR_PERS_KTILE_B(CUR, NXT)                                                                                    \
     {                                                                                                                  \
         const unsigned so = (unsigned)((g & 3) * STAGE), sn = (unsigned)(((g + 1) & 3) * STAGE);                        \
-        MOCR_W2_READ_TAIL(CUR, offA + so);                                                                             \
+        MOCR_W2_READ_TAIL(CUR, offA + so - hadj);                                                                             \
         asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(CUR.fb[0]), "+v"(CUR.fb[1]), "+v"(CUR.fb[2]), "+v"(CUR.fb[3]),      \
                      "+v"(CUR.fa[0]), "+v"(CUR.fa[1]));                                                                \
         MOCR_W2_GROUP(CUR, 0);                                                                                         \
@@ -271,9 +300,11 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
         __builtin_amdgcn_s_barrier();                                                                                  \
         asm volatile("" ::: "memory");                                                                                 \
         stage_next();                                     /* K-tile g + 3 into the slot of K-tile g - 1 */              \
-        MOCR_W2_READ_HEAD(NXT, offA + sn, offB + sn);                                                                  \
-        MOCR_W2_GROUP(CUR, 2);                                                                                         \
-        MOCR_W2_GROUP(CUR, 3);                                                                                         \
+        MOCR_W2_READ_HEAD(NXT, offA + sn - hadj_h, offB + sn);      /* K-tile g + 1: the NEXT tile's when this is the tile's last */ \
+        if (!(STRIP && half)) {                                                                                        \
+            MOCR_W2_GROUP(CUR, 2);                                                                                     \
+            MOCR_W2_GROUP(CUR, 3);                                                                                     \
+        }                                                                                                              \
         ++g;                                                                                                           \
     }
 
@@ -281,7 +312,11 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
         int m0, n0, row_lo, row_hi;
         bool half;
         tile_desc(tile, m0, n0, row_lo, row_hi, half);
-        const unsigned own_lo = (unsigned)(row_lo - m0), own_n = (unsigned)(row_hi - row_lo);      // the tile's own rows, window-relative
+        [[maybe_unused]] const unsigned own_lo = (unsigned)(row_lo - m0), own_n = (unsigned)(row_hi - row_lo);      // STRIP: the tile's rows inside the window
+        if constexpr (STRIP) {
+            hadj = half ? hadj_unit : 0u;
+            hadj_nx = (tile + tstride == s_hpos) ? hadj_unit : 0u;
+        }
         // bias of this lane's 16 columns: requested here, used in the epilogue (a load in front of the K loop instead of
         // a round trip in the epilogue)
         // (EPI_BIAS_RESID: every register counts there - the bias is added by the store waves instead, to whole rows: a
@@ -298,27 +333,25 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
                 bias[j][0] = bv.x; bias[j][1] = bv.y; bias[j][2] = bv.z; bias[j][3] = bv.w;
             }
         }
-        if (STRIP && half && wm == 0) {
-            // half tile: rows 0..127 of the window belong to another tile - these waves (0-3: the DMA waves) only keep the
-            // ring and the barriers going, in the order of the two macros above
+        if constexpr (STRIP) {
             for (int t = 0; t < nt; t += 2) {
-                stage_next();
-                ++g;
-                if (issues_dma) wait_vmcnt<0>();
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                stage_next();
-                ++g;
+                const unsigned hadj_h = t + 2 < nt ? hadj : hadj_nx;      // the tile of the K-tile behind this pair
+                if constexpr (PAIR) {
+                    MOCR_PERS_KTILE_A(P, Q)
+                    MOCR_PERS_KTILE_B(Q, P)
+                } else {
+                    { const unsigned hadj_k = hadj; MOCR_PERS_KTILE(P, Q) }
+                    { const unsigned hadj_k = hadj_h; MOCR_PERS_KTILE(Q, P) }
+                }
             }
-            // the first six fragments of the next tile's first K-tile (landed: the last barrier), as the other waves' last
-            // K-tile requested them
-            MOCR_W2_READ_HEAD(P, offA + (unsigned)((g & 3) * STAGE), offB + (unsigned)((g & 3) * STAGE));
         } else if constexpr (PAIR) {
+            constexpr unsigned hadj_h = 0;
             for (int t = 0; t < nt; t += 2) {
                 MOCR_PERS_KTILE_A(P, Q)
                 MOCR_PERS_KTILE_B(Q, P)
             }
         } else {
+            constexpr unsigned hadj_k = 0;
             for (int t = 0; t < nt; t += 2) {
                 MOCR_PERS_KTILE(P, Q)
                 MOCR_PERS_KTILE(Q, P)
@@ -342,6 +375,32 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
         char* const piece0 = smem + RING;
         char* const piece1 = smem + ((g - 1) & 3) * STAGE;
         if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
+            [[maybe_unused]] float cs[4][4], mu[8], rs[8];
+            if constexpr (LNF) {
+                // column sums of this lane's 16 columns and the statistics of its 8 rows (16 i + l15 of the wave's 128):
+                // requested here, not in front of the K loop (no register is free there); addresses laundered so that
+                // hipcc does not hoist them
+                const float* csrc = p.csum + n0 + wn * 64 + 4 * g4;
+                const float* psrc = p.ln_part;
+                asm volatile("" : "+v"(csrc), "+s"(psrc));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 cv = *reinterpret_cast<const float4*>(csrc + 16 * j);
+                    cs[j][0] = cv.x; cs[j][1] = cv.y; cs[j][2] = cv.z; cs[j][3] = cv.w;
+                }
+                const float inv_k = 1.0f / (float)p.k_per_split;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    int m = m0 + wm * 128 + 16 * i + l15;
+                    if (guard && m >= p.M) m = p.M - 1;
+                    const float4 pa = *reinterpret_cast<const float4*>(psrc + (size_t)m * 8);
+                    const float4 pb = *reinterpret_cast<const float4*>(psrc + (size_t)m * 8 + 4);
+                    const float mean = ((pa.x + pa.z) + (pb.x + pb.z)) * inv_k;
+                    const float var = fmaxf(((pa.y + pa.w) + (pb.y + pb.w)) * inv_k - mean * mean, 0.f);
+                    mu[i] = mean;
+                    rs[i] = 1.0f / sqrtf(var + p.ln_eps);
+                }
+            }
             // two passes of 128 rows x 512 B: pass h takes rows 64h .. 64h+63 of each wave's 128 (m-tiles 4h .. 4h+3);
             // staging row sr = 64 wm + (row within the 64): rows 0-63 in piece0, 64-127 in piece1;
             // 16-byte chunk c of staging row sr at chunk c ^ (sr & 15)
@@ -357,7 +416,8 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
                         float v[4];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            v[r] = acc[j][i][r] + bias[j][r];
+                            if constexpr (LNF) v[r] = fmaf(rs[i], fmaf(-mu[i], cs[j][r], acc[j][i][r]), bias[j][r]);
+                            else v[r] = acc[j][i][r] + bias[j][r];
                             if constexpr (EPI == EPI_BIAS_GELU) { if (!(ablate & 32)) v[r] = gelu_fast(v[r]); }
                             acc[j][i][r] = 0.f;
                         }
@@ -408,9 +468,15 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
             // fp32 (the residual is already in the sums): four passes of 64 rows x 1 KiB: pass q takes m-tiles 2q, 2q+1 (32
             // rows) of each wave; staging row sr = 32 wm + (row within the 32): rows 0-31 in piece0, 32-63 in piece1;
             // 16-byte chunk c (0..63) of staging row sr at chunk c ^ (sr & 15)
-            const int nxt = tile + tstride;
+            // (laundered like `ldo`: the next tile's residual addresses are not to be computed above the K loop)
+            int nxt = tile + tstride;
+            asm volatile("" : "+s"(nxt));
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
+                if (STRIP && q >= 2 && half) {        // a half tile's wave holds m-tiles 0..3 only (window rows 64 wm + 16 i)
+                    if (nxt < tile_end) { load_resid(nxt, 2 * q); load_resid(nxt, 2 * q + 1); }
+                    continue;
+                }
 #pragma unroll
                 for (int ii = 0; ii < 2; ++ii) {
                     const int i = 2 * q + ii;
@@ -446,14 +512,53 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
                             __builtin_amdgcn_s_barrier();                // read back: the staging area may be rewritten
                             asm volatile("" ::: "memory");
                         }
+                        const int rstep = STRIP && half ? 64 : 128;
+                        [[maybe_unused]] float a1[8], a2[8];
 #pragma unroll
                         for (int it = 0; it < 8; ++it) {
                             const int sr = 16 * sw + 8 * hf + it;
-                            const int row = (sr >> 5) * 128 + 32 * q + (sr & 31);
+                            const int row = (sr >> 5) * rstep + 32 * q + (sr & 31);
                             const bool mine = STRIP ? (unsigned)row - own_lo < own_n : (!guard || m0 + row < p.M);
-                            if (mine && !(ablate & 8))
-                                *reinterpret_cast<float4*>(obase + (size_t)row * ldo) =
-                                    make_float4(v[it].x + bias_row.x, v[it].y + bias_row.y, v[it].z + bias_row.z, v[it].w + bias_row.w);
+                            const float4 o = make_float4(v[it].x + bias_row.x, v[it].y + bias_row.y, v[it].z + bias_row.z, v[it].w + bias_row.w);
+                            if (mine && !(ablate & 8)) {
+                                *reinterpret_cast<float4*>(obase + (size_t)row * ldo) = o;
+                                if constexpr (LNF) {
+                                    uint2 u;
+                                    u.x = pack_bf16x2(o.x, o.y); u.y = pack_bf16x2(o.z, o.w);
+                                    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.xb) + (size_t)(m0 + row) * ldo + n0 + 4 * lane) = u;
+                                }
+                            }
+                            if constexpr (LNF) {
+                                a1[it] = (o.x + o.y) + (o.z + o.w);
+                                a2[it] = fmaf(o.x, o.x, o.y * o.y) + fmaf(o.z, o.z, o.w * o.w);
+                            }
+                        }
+                        if constexpr (LNF) {
+                            // eight rows' sums over the wave in 10 exchanges per quantity: halves of the wave take halves of the
+                            // rows (xor 32, 16, 8), then three plain steps; lanes 8 k hold row 4 b5 + 2 b4 + b3 of their lane number
+                            const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8;
+                            float b1[4], b2[4], c1[2], c2[2];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                b1[r] = (h5 ? a1[r + 4] : a1[r]) + __shfl_xor(h5 ? a1[r] : a1[r + 4], 32, 64);
+                                b2[r] = (h5 ? a2[r + 4] : a2[r]) + __shfl_xor(h5 ? a2[r] : a2[r + 4], 32, 64);
+                            }
+#pragma unroll
+                            for (int r = 0; r < 2; ++r) {
+                                c1[r] = (h4 ? b1[r + 2] : b1[r]) + __shfl_xor(h4 ? b1[r] : b1[r + 2], 16, 64);
+                                c2[r] = (h4 ? b2[r + 2] : b2[r]) + __shfl_xor(h4 ? b2[r] : b2[r + 2], 16, 64);
+                            }
+                            float d1 = (h3 ? c1[1] : c1[0]) + __shfl_xor(h3 ? c1[0] : c1[1], 8, 64);
+                            float d2 = (h3 ? c2[1] : c2[0]) + __shfl_xor(h3 ? c2[0] : c2[1], 8, 64);
+                            d1 += __shfl_xor(d1, 4, 64); d2 += __shfl_xor(d2, 4, 64);
+                            d1 += __shfl_xor(d1, 2, 64); d2 += __shfl_xor(d2, 2, 64);
+                            d1 += __shfl_xor(d1, 1, 64); d2 += __shfl_xor(d2, 1, 64);
+                            const int it_l = (h5 ? 4 : 0) + (h4 ? 2 : 0) + (h3 ? 1 : 0);
+                            const int sr_l = 16 * sw + 8 * hf + it_l;
+                            const int row_l = (sr_l >> 5) * rstep + 32 * q + (sr_l & 31);
+                            const bool mine_l = STRIP ? (unsigned)row_l - own_lo < own_n : (!guard || m0 + row_l < p.M);
+                            if ((lane & 7) == 0 && mine_l && !(ablate & 8))
+                                *reinterpret_cast<float2*>(p.ln_part + (size_t)(m0 + row_l) * 8 + (n0 >> 8) * 2) = make_float2(d1, d2);
                         }
                     }
                 } else {

@@ -140,6 +140,36 @@ def test_gemm_persistent_blocks_walk_several_tiles(epi, tile, M, N, K):
     report(f"persistent gemm tile{tile} M{M} N{N} K{K} epi{epi}: max rel err {err:.3e} (tol {tol:.1e})")
 
 
+@pytest.mark.parametrize("tile,M,N,K", [(4099, 50432, 768, 768), (4099, 33000, 768, 768), (4099, 8900, 2304, 768), (4099, 20000, 768, 3072),
+                                        (4100, 2500, 768, 3072), (4100, 2200, 768, 128), (4100, 1000, 1024, 256), (4100, 300, 768, 256)] +
+                         ([(4103, 50432, 768, 3072), (4103, 33000, 768, 768), (4104, 2500, 768, 3072), (4104, 2200, 768, 128)] if LAB else []))
+def test_gemm_persistent_strip_schedule(tile, M, N, K):
+    """gemm_pers_kernel's strip schedule (tile code 4099; 4100 = on 8 blocks), the fp32-residual GEMMs of the encoder: a block
+    owns a strip of rows of one 256-column slice - 256-row tiles plus one HALF tile (a wave multiplies 64 x 64) first, in the
+    middle or last, windows shifted up where a tile is short.  50,432 x 768: the encoder's own shape (85 strips of 592 / 608
+    rows: two tiles + a half tile of 80 / 96 rows); 33,000 rows: remainders of 128 (half) and 144 rows (short full tile), M
+    not a multiple of 16; N = 2304: strips made of the XCDs' left-over blocks; 8 blocks: two or three strips of 4-5 tiles;
+    300 rows: one short tile per strip, its window shifted up.  In place (out = resid, as the encoder calls it); every element against float64."""
+    eng = engine("bf16")
+    rs = np.random.RandomState(M + N + K + tile)
+    A = bf16_round(rs.standard_normal((M, K)).astype(np.float32))          # NOT padded: the strip schedule reads no row behind M
+    W = bf16_round((rs.standard_normal((N, K)) * 0.05).astype(np.float32))
+    bias = rs.standard_normal(N).astype(np.float32)
+    resid = rs.standard_normal((M, N)).astype(np.float32)
+    ref = A.astype(np.float64) @ W.astype(np.float64).T + bias + resid
+    dA, dW, dB = _dev(A, "bf16"), _dev(W, "bf16"), torch.from_numpy(bias).cuda()
+    for rep in range(2):
+        dO = torch.full((M + 3, N), float("nan"), device="cuda", dtype=torch.float32)      # 3 guard rows behind the output
+        dO[:M] = torch.from_numpy(resid).cuda()
+        torch.cuda.synchronize()
+        eng.op_gemm(dA, dW, dB, dO, dO, M, N, K, EPI_BIAS_RESID, tile=tile, split_k=1)
+        got = dO.float().cpu().numpy().astype(np.float64)
+        assert np.isnan(got[M:]).all(), "rows behind M were written"
+        err = np.abs(got[:M] - ref).max() / np.abs(ref).max()
+        assert np.isfinite(got[:M]).all() and err <= 1e-5, f"rep {rep}: max rel err {err:.3e}"
+    report(f"persistent gemm, strips, tile{tile} M{M} N{N} K{K}: max rel err {err:.3e} (tol 1.0e-05)")
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("M,N,K,split", [(64, 768, 768, 12), (37, 2304, 768, 4), (128, 768, 3072, 16), (64, 6144, 768, 2)])
 def test_gemm_split_k_slabs(dtype, M, N, K, split):
