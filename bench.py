@@ -124,6 +124,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=48, help="crops per regime the CPU baseline (oracle) decodes: ~15-20 s of CPU work in all")
     ap.add_argument("--fp8-attention", action="store_true",
                     help="opt-in mode of BASELINE configs[4]: e4m3 key/value rows + fp8 MFMA in the decode attention (not the parity configuration)")
+    ap.add_argument("--engine-flags", type=int, default=0, help="extra mocr_config.flags bits (A/B runs, e.g. 512 = MOCR_FLAG_NO_LN_FOLD)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config4", action="store_true", help="skip the variable-resolution + fp8-attention record")
     ap.add_argument("--no-profile", action="store_true")
@@ -167,7 +168,7 @@ def main():
     weights = synthetic_weights(0)
     args.max_batch = max(args.max_batch, args.batch)
     eng = Engine(weights, spec, dtype=args.dtype, device=local, max_batch=args.max_batch, lanes=args.lanes,
-                 flags=128 if args.fp8_attention else 0)
+                 flags=(128 if args.fp8_attention else 0) | args.engine_flags)
     dtype_label = args.dtype + ("+fp8attn" if args.fp8_attention else "")
     B, L = args.batch, args.max_len
     strong = args.queue > 0

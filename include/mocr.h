@@ -58,8 +58,10 @@ enum {
     MOCR_FLAG_LATENT_ALWAYS = 1 << 6,     /* bf16: latent attention for every batch size (default: batches of <= 384 rows take the
                                            * classic projected-K/V kernels, whose grid - one block per (row, head) - has half the
                                            * step latency there: 50 instead of 80 ms for 64 crops) */
-    MOCR_FLAG_NO_SMALL_BATCH_PATH = 1 << 8 /* bf16: batches of <= 32 rows through the generic split-K projections + add/LayerNorm
+    MOCR_FLAG_NO_SMALL_BATCH_PATH = 1 << 8, /* bf16: batches of <= 32 rows through the generic split-K projections + add/LayerNorm
                                            * launches (28 per decode step) instead of the one-launch-per-projection path (19) */
+    MOCR_FLAG_NO_LN_FOLD = 1 << 9         /* bf16: the encoder's LayerNorms as launches of their own even where the layer GEMMs run on
+                                           * the persistent kernel (default there: folded into the GEMMs on both sides of them) */
 };
 
 typedef struct mocr_engine mocr_engine;
@@ -190,6 +192,15 @@ int mocr_op_gemm(mocr_engine* e, const void* dA, const void* dW, const float* d_
                  int32_t tile, int32_t split_k);
 int mocr_op_layernorm(mocr_engine* e, const float* d_x, const float* d_gamma, const float* d_beta,
                       void* d_out, int32_t M);
+/* bf16 engines: the persistent encoder GEMM (tile 4096 / 4097 / 4099 / 4100) with the LayerNorm folded in.
+ * epilogue 3 (bias + residual, fp32 out): also writes d_xb [M,N] bf16 = the output rows and d_part [M,4,2] float32 = each
+ * row's (sum, sum of squares) per 256-column slice.  epilogue 1 / 2 (bias / bias + GELU, bf16 out): dA = the rows x as bf16,
+ * dW = bf16(W o gamma), d_bias = b + W beta, d_csum [N] = column sums of dW, d_part = the statistics of the fp32 rows:
+ * out = LN(x) W^T + b.  mocr_op_ln_prep: d_x [M,768] float32 -> d_xb bf16 + d_part (partial 0 = the row's sums). */
+int mocr_op_gemm_ln(mocr_engine* e, const void* dA, const void* dW, const float* d_bias, void* d_out,
+                    const float* d_resid, int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t tile,
+                    float* d_part, const float* d_csum, void* d_xb);
+int mocr_op_ln_prep(mocr_engine* e, const float* d_x, void* d_xb, float* d_part, int32_t M);
 int mocr_op_enc_attention(mocr_engine* e, const void* d_qkv, void* d_ctx, int32_t n, int32_t impl);
 /* Latent decode attention (bf16 engines): d_qt [n,16,768], keys d_x with x_batch_stride elements between
  * sequences, context length len for every row; d_out [n,16,768] = softmax(qt . x^T) x per head. */

@@ -64,6 +64,13 @@ static inline uint16_t host_f2bf(float f) {
     return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
 
+static inline float host_bf2f(uint16_t h) {
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
 struct EncLayerW {
     void *wqkv, *wo, *w1, *w2;
     float *bqkv, *bo, *b1, *b2, *ln1g, *ln1b, *ln2g, *ln2b;
@@ -652,6 +659,15 @@ void run_encoder(mocr_engine* e, const uint8_t* d_gray, int n) {
         if ((long long)M * D * split_o > e->slab_cap) split_o = 1;
         if (split_2 < 2) split_2 = 1;
     }
+    // bf16, all four layer GEMMs on the persistent kernel: the 24 LayerNorms between them are FOLDED into those GEMMs
+    // (kernels_gemm_pers.h LNF; r03: 25 launches of 38-40 us were 7.5 % of the encoder at batch 256).  Xn then holds x itself
+    // as bf16; only the final LayerNorm (the encoder's output) is a launch.
+    bool fold = false;
+    if constexpr (sizeof(T) == 2) {
+        static const int fold_env = env_int("MOCR_ENC_LN_FOLD", 1);
+        fold = fold_env && !(e->cfg.flags & MOCR_FLAG_NO_LN_FOLD) && ETQ == 4096 && ETO == 4096 && ET1 == 4096 && ET2 == 4096 &&
+               D == 768 && w.enc[0].wqkv_f;
+    }
     const float* pend_bias = nullptr;      // bias of a split GEMM whose slabs the next LayerNorm has to add to X
     int pend_slabs = 0;
     auto norm = [&](const float* g, const float* b, void* out) {
@@ -662,6 +678,29 @@ void run_encoder(mocr_engine* e, const uint8_t* d_gray, int n) {
         HIPCHECK(hipGetLastError());
         pend_slabs = 0;
     };
+    if (fold) {
+        {
+            ProfScope ps(e, "ln_prep", 0, (double)M * D * 6);
+            hipLaunchKernelGGL((ln_prep_kernel<768>), dim3((M + 3) / 4), dim3(256), 0, e->stream, e->X, reinterpret_cast<bf16_t*>(e->Xn),
+                               e->ln_part, M);
+            HIPCHECK(hipGetLastError());
+        }
+        for (int l = 0; l < e->cfg.enc_layers; ++l) {
+            const EncLayerW& L = w.enc[l];
+            LnFold use_q{e->ln_part, L.sqkv, nullptr}, use_1{e->ln_part, L.s1, nullptr}, emit{e->ln_part, nullptr, e->Xn};
+            gemm<T>(e, "gemm_enc_qkv", e->Xn, D, L.wqkv_f, L.bqkv_f, e->QKV, 3 * D, nullptr, M, 3 * D, D, EPI_BIAS, ETQ, 1, 0, nullptr, 0, nullptr,
+                    9, nullptr, &use_q);
+            enc_attention<T>(e, e->QKV, e->CTX, n, impl);
+            gemm<T>(e, "gemm_enc_oproj", e->CTX, D, L.wo, L.bo, e->X, D, e->X, M, D, D, EPI_BIAS_RESID, ETO, 1, 0, nullptr, 0, nullptr, 0,
+                    nullptr, &emit);
+            gemm<T>(e, "gemm_enc_fc1", e->Xn, D, L.w1_f, L.b1_f, e->Hb, F, nullptr, M, F, D, EPI_BIAS_GELU, ET1, 1, 0, nullptr, 0, nullptr, 12,
+                    nullptr, &use_1);
+            gemm<T>(e, "gemm_enc_fc2", e->Hb, F, L.w2, L.b2, e->X, D, e->X, M, D, F, EPI_BIAS_RESID, ET2, 1, 0, nullptr, 0, nullptr, 0,
+                    nullptr, &emit);
+        }
+        norm(w.lnfg, w.lnfb, e->ENC);
+        return;
+    }
     for (int l = 0; l < e->cfg.enc_layers; ++l) {
         const EncLayerW& L = w.enc[l];
         norm(L.ln1g, L.ln1b, e->Xn);
@@ -1449,6 +1488,34 @@ void commit_weights(mocr_engine* e) {
         L.b1 = up.f32(up.get(p + "mlp.fc1.bias", {F}));
         L.w2 = up.mat(up.get(p + "mlp.fc2.weight", {D, F}));
         L.b2 = up.f32(up.get(p + "mlp.fc2.bias", {D}));
+        if (c.dtype == MOCR_BF16) {
+            // LN(x) W^T + b = rstd (x (W o gamma)^T - mean colsum) + (b + W beta): the folded operands (colsum of the ROUNDED
+            // folded weight - what the MFMAs multiply -, in double)
+            auto fold = [&](const std::vector<float>& W, const std::vector<float>& b, const std::vector<float>& g, const std::vector<float>& be,
+                            int64_t N, void*& wf, float*& cs, float*& bf) {
+                std::vector<float> Wf((size_t)N * D), csum(N), bias(N);
+                for (int64_t n = 0; n < N; ++n) {
+                    double sc = 0.0, sb = 0.0;
+                    for (int64_t k = 0; k < D; ++k) {
+                        const float v = W[n * D + k] * g[k];
+                        Wf[n * D + k] = v;
+                        sc += (double)host_bf2f(host_f2bf(v));
+                        sb += (double)W[n * D + k] * (double)be[k];
+                    }
+                    csum[n] = (float)sc;
+                    bias[n] = (float)((double)b[n] + sb);
+                }
+                wf = up.mat(Wf); cs = up.f32(csum); bf = up.f32(bias);
+            };
+            const auto wqkv_h = concat({&up.get(p + "attention.q_proj.weight", {D, D}), &up.get(p + "attention.k_proj.weight", {D, D}),
+                                        &up.get(p + "attention.v_proj.weight", {D, D})});
+            const auto bqkv_h = concat({&up.get(p + "attention.q_proj.bias", {D}), &up.get(p + "attention.k_proj.bias", {D}),
+                                        &up.get(p + "attention.v_proj.bias", {D})});
+            fold(wqkv_h, bqkv_h, up.get(p + "layernorm_before.weight", {D}), up.get(p + "layernorm_before.bias", {D}), 3 * D,
+                 L.wqkv_f, L.sqkv, L.bqkv_f);
+            fold(up.get(p + "mlp.fc1.weight", {F, D}), up.get(p + "mlp.fc1.bias", {F}), up.get(p + "layernorm_after.weight", {D}),
+                 up.get(p + "layernorm_after.bias", {D}), F, L.w1_f, L.s1, L.b1_f);
+        }
     }
     w.lnfg = up.f32(up.get("encoder.layernorm.weight", {D}));
     w.lnfb = up.f32(up.get("encoder.layernorm.bias", {D}));
@@ -2206,6 +2273,33 @@ int mocr_op_gemm(mocr_engine* e, const void* dA, const void* dW, const float* d_
             gemm<bf16_t>(e, "op_gemm", dA, K, dW, d_bias, d_out, N, d_resid, M, N, K, epilogue, tile, split_k, slab);
         else
             gemm<float>(e, "op_gemm", dA, K, dW, d_bias, d_out, N, d_resid, M, N, K, epilogue, tile, split_k, slab);
+        HIPCHECK(hipStreamSynchronize(e->stream));
+    });
+}
+
+int mocr_op_gemm_ln(mocr_engine* e, const void* dA, const void* dW, const float* d_bias, void* d_out, const float* d_resid,
+                    int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t tile, float* d_part, const float* d_csum, void* d_xb) {
+    return guarded(e, [&] {
+        std::lock_guard<std::mutex> lk(e->mu);
+        HIPCHECK(hipSetDevice(e->cfg.device));
+        drive(e);
+        e->bind(0);
+        if (e->cfg.dtype != MOCR_BF16) throw ArgError{"mocr_op_gemm_ln: bf16 engines only", MOCR_ERR_UNSUPPORTED};
+        LnFold f{d_part, d_csum, d_xb};
+        gemm<bf16_t>(e, "op_gemm_ln", dA, K, dW, d_bias, d_out, N, d_resid, M, N, K, epilogue, tile, 1, 0, nullptr, 0, nullptr, 0, nullptr, &f);
+        HIPCHECK(hipStreamSynchronize(e->stream));
+    });
+}
+
+int mocr_op_ln_prep(mocr_engine* e, const float* d_x, void* d_xb, float* d_part, int32_t M) {
+    return guarded(e, [&] {
+        std::lock_guard<std::mutex> lk(e->mu);
+        HIPCHECK(hipSetDevice(e->cfg.device));
+        drive(e);
+        e->bind(0);
+        if (e->D != 768) throw ArgError{"mocr_op_ln_prep: hidden size 768 only", MOCR_ERR_UNSUPPORTED};
+        hipLaunchKernelGGL((ln_prep_kernel<768>), dim3((M + 3) / 4), dim3(256), 0, e->stream, d_x, reinterpret_cast<bf16_t*>(d_xb), d_part, M);
+        HIPCHECK(hipGetLastError());
         HIPCHECK(hipStreamSynchronize(e->stream));
     });
 }

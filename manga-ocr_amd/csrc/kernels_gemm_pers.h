@@ -24,6 +24,22 @@
 #pragma once
 #include "kernels_gemm.h"
 
+// cross-lane helpers of the LayerNorm statistics (gfx950: v_permlane32_swap / v_permlane16_swap, DPP)
+typedef unsigned mocr_u32x2 __attribute__((ext_vector_type(2)));
+// lanes 0-31: a[l] + a[l + 32]; lanes 32-63: b[l - 32] + b[l]
+__device__ __forceinline__ float swap32_sum(float a, float b) {
+    const mocr_u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+// 16-lane rows 0 and 2: a[l] + a[l + 16]; rows 1 and 3: b[l - 16] + b[l]
+__device__ __forceinline__ float swap16_sum(float a, float b) {
+    const mocr_u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+template <int CTRL> __device__ __forceinline__ float dpp_f32(float v) {
+    return __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), CTRL, 0xf, 0xf, false));
+}
+
 constexpr int PERS_LDS = 160 * 1024;      // four 32 KiB ring slots + 32 KiB that only the epilogue uses
 
 // SPLIT_DMA: the LDS-DMA of a K-tile is requested by waves 0-3 alone (8 pieces each; those waves then never have a
@@ -323,8 +339,23 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
         // lane then needs the four values of its own columns only)
         float bias[4][4];
         float4 bias_row = make_float4(0.f, 0.f, 0.f, 0.f);
+        // LNF (the GEMM behind a LayerNorm): the row statistics and the column constants are requested HERE by the store
+        // waves alone - lane l of store wave sw: row 64 sw + l of the tile and column 64 sw + l - and handed to every wave
+        // through LDS in the epilogue.  A DMA wave must not load anything in its epilogue: the load queues behind the next
+        // tile's K-tiles and its wait holds until they have landed (r03: +2 us per tile).
+        [[maybe_unused]] float4 st_a, st_b;
+        [[maybe_unused]] float cs_l = 0.f, bias_l = 0.f;
         if constexpr (EPI == EPI_BIAS_RESID) {
             if (!dma_wave) bias_row = *reinterpret_cast<const float4*>(p.bias + n0 + 4 * lane);
+        } else if constexpr (LNF) {
+            if (!dma_wave) {
+                int m = m0 + 64 * sw + lane;
+                if (guard && m >= p.M) m = p.M - 1;
+                st_a = *reinterpret_cast<const float4*>(p.ln_part + (size_t)m * 8);
+                st_b = *reinterpret_cast<const float4*>(p.ln_part + (size_t)m * 8 + 4);
+                cs_l = p.csum[n0 + 64 * sw + lane];
+                bias_l = p.bias[n0 + 64 * sw + lane];
+            }
         } else {
             const float* bsrc = p.bias + n0 + wn * 64 + 4 * g4;
 #pragma unroll
@@ -361,11 +392,21 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
         // LDS free right now: the slot of the K-tile just multiplied, (g - 1) & 3 (every wave passed that K-tile's barrier
         // with all its fragments in registers), and the spare 32 KiB.  K-tiles g, g + 1, g + 2 of the NEXT tile sit in the
         // other three slots (landed / in flight); P holds the first six fragments of K-tile g already.
+        if constexpr (LNF || STRIP) {
+            // The LayerNorm-folding epilogues need ~30 registers more than the plain ones (the strip schedule a few), and a spill in this kernel is a
+            // scratch LOAD in a DMA wave's queue: its wait drains the ring.  The first six fragments of the next K-tile (24
+            // registers, requested by the last K-tile) are given up here and requested again behind the epilogue.
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(P.fb[0]), "+v"(P.fb[1]), "+v"(P.fb[2]), "+v"(P.fb[3]), "+v"(P.fa[0]), "+v"(P.fa[1]));
+        }
         if (ablate & 4) {                      // diagnostics: no epilogue
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int i = 0; i < 8; ++i) { asm volatile("" :: "v"(acc[j][i])); acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            if constexpr (LNF || STRIP) {
+                const unsigned sg = (unsigned)((g & 3) * STAGE);
+                MOCR_W2_READ_HEAD(P, offA + sg - hadj_nx, offB + sg);
+            }
             continue;
         }
         // (the row stride is laundered per tile: hipcc otherwise hoists every row's `row * ldo` out of the tile loop - 17
@@ -377,29 +418,34 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
         if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
             [[maybe_unused]] float cs[4][4], mu[8], rs[8];
             if constexpr (LNF) {
-                // column sums of this lane's 16 columns and the statistics of its 8 rows (16 i + l15 of the wave's 128):
-                // requested here, not in front of the K loop (no register is free there); addresses laundered so that
-                // hipcc does not hoist them
-                const float* csrc = p.csum + n0 + wn * 64 + 4 * g4;
-                const float* psrc = p.ln_part;
-                asm volatile("" : "+v"(csrc), "+s"(psrc));
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float4 cv = *reinterpret_cast<const float4*>(csrc + 16 * j);
-                    cs[j][0] = cv.x; cs[j][1] = cv.y; cs[j][2] = cv.z; cs[j][3] = cv.w;
+                // through the spare 32 KiB (free until the first staging write): [256] (mean, rstd) of the tile's rows, then
+                // [256] (column sum, bias) of its columns
+                float* const sst = reinterpret_cast<float*>(piece0);
+                if (!dma_wave) {
+                    const float inv_k = 1.0f / (float)p.k_per_split;
+                    const float mean = ((st_a.x + st_a.z) + (st_b.x + st_b.z)) * inv_k;
+                    const float var = fmaxf(((st_a.y + st_a.w) + (st_b.y + st_b.w)) * inv_k - mean * mean, 0.f);
+                    *reinterpret_cast<float2*>(sst + 2 * (64 * sw + lane)) = make_float2(mean, 1.0f / sqrtf(var + p.ln_eps));
+                    *reinterpret_cast<float2*>(sst + 512 + 2 * (64 * sw + lane)) = make_float2(cs_l, bias_l);
                 }
-                const float inv_k = 1.0f / (float)p.k_per_split;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    int m = m0 + wm * 128 + 16 * i + l15;
-                    if (guard && m >= p.M) m = p.M - 1;
-                    const float4 pa = *reinterpret_cast<const float4*>(psrc + (size_t)m * 8);
-                    const float4 pb = *reinterpret_cast<const float4*>(psrc + (size_t)m * 8 + 4);
-                    const float mean = ((pa.x + pa.z) + (pb.x + pb.z)) * inv_k;
-                    const float var = fmaxf(((pa.y + pa.w) + (pb.y + pb.w)) * inv_k - mean * mean, 0.f);
-                    mu[i] = mean;
-                    rs[i] = 1.0f / sqrtf(var + p.ln_eps);
+                    const float2 mr = *reinterpret_cast<const float2*>(sst + 2 * (wm * 128 + 16 * i + l15));
+                    mu[i] = mr.x; rs[i] = mr.y;
                 }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 c0 = *reinterpret_cast<const float4*>(sst + 512 + 2 * (wn * 64 + 16 * j + 4 * g4));
+                    const float4 c1 = *reinterpret_cast<const float4*>(sst + 512 + 2 * (wn * 64 + 16 * j + 4 * g4) + 4);
+                    cs[j][0] = c0.x; bias[j][0] = c0.y; cs[j][1] = c0.z; bias[j][1] = c0.w;
+                    cs[j][2] = c1.x; bias[j][2] = c1.y; cs[j][3] = c1.z; bias[j][3] = c1.w;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                 // read: the staging passes may write the spare area
+                asm volatile("" ::: "memory");
             }
             // two passes of 128 rows x 512 B: pass h takes rows 64h .. 64h+63 of each wave's 128 (m-tiles 4h .. 4h+3);
             // staging row sr = 64 wm + (row within the 64): rows 0-63 in piece0, 64-127 in piece1;
@@ -522,7 +568,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
                             const float4 o = make_float4(v[it].x + bias_row.x, v[it].y + bias_row.y, v[it].z + bias_row.z, v[it].w + bias_row.w);
                             if (mine && !(ablate & 8)) {
                                 *reinterpret_cast<float4*>(obase + (size_t)row * ldo) = o;
-                                if constexpr (LNF) {
+                                if (LNF && !(ablate & 64)) {
                                     uint2 u;
                                     u.x = pack_bf16x2(o.x, o.y); u.y = pack_bf16x2(o.z, o.w);
                                     *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.xb) + (size_t)(m0 + row) * ldo + n0 + 4 * lane) = u;
@@ -533,26 +579,21 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
                                 a2[it] = fmaf(o.x, o.x, o.y * o.y) + fmaf(o.z, o.z, o.w * o.w);
                             }
                         }
-                        if constexpr (LNF) {
-                            // eight rows' sums over the wave in 10 exchanges per quantity: halves of the wave take halves of the
-                            // rows (xor 32, 16, 8), then three plain steps; lanes 8 k hold row 4 b5 + 2 b4 + b3 of their lane number
+                        if (LNF && !(ablate & 128)) {
+                            // eight rows' sums over the wave: halves of the wave take halves of the rows (v_permlane32_swap,
+                            // v_permlane16_swap, row_ror:8), then three plain DPP steps; lanes 8 k hold row 4 b5 + 2 b4 + b3 of their
+                            // lane number
                             const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8;
                             float b1[4], b2[4], c1[2], c2[2];
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                b1[r] = (h5 ? a1[r + 4] : a1[r]) + __shfl_xor(h5 ? a1[r] : a1[r + 4], 32, 64);
-                                b2[r] = (h5 ? a2[r + 4] : a2[r]) + __shfl_xor(h5 ? a2[r] : a2[r + 4], 32, 64);
-                            }
+                            for (int r = 0; r < 4; ++r) { b1[r] = swap32_sum(a1[r], a1[r + 4]); b2[r] = swap32_sum(a2[r], a2[r + 4]); }
 #pragma unroll
-                            for (int r = 0; r < 2; ++r) {
-                                c1[r] = (h4 ? b1[r + 2] : b1[r]) + __shfl_xor(h4 ? b1[r] : b1[r + 2], 16, 64);
-                                c2[r] = (h4 ? b2[r + 2] : b2[r]) + __shfl_xor(h4 ? b2[r] : b2[r + 2], 16, 64);
-                            }
-                            float d1 = (h3 ? c1[1] : c1[0]) + __shfl_xor(h3 ? c1[0] : c1[1], 8, 64);
-                            float d2 = (h3 ? c2[1] : c2[0]) + __shfl_xor(h3 ? c2[0] : c2[1], 8, 64);
-                            d1 += __shfl_xor(d1, 4, 64); d2 += __shfl_xor(d2, 4, 64);
-                            d1 += __shfl_xor(d1, 2, 64); d2 += __shfl_xor(d2, 2, 64);
-                            d1 += __shfl_xor(d1, 1, 64); d2 += __shfl_xor(d2, 1, 64);
+                            for (int r = 0; r < 2; ++r) { c1[r] = swap16_sum(b1[r], b1[r + 2]); c2[r] = swap16_sum(b2[r], b2[r + 2]); }
+                            float d1 = (h3 ? c1[1] : c1[0]) + dpp_f32<0x128>(h3 ? c1[0] : c1[1]);      // row_ror:8 = lane ^ 8
+                            float d2 = (h3 ? c2[1] : c2[0]) + dpp_f32<0x128>(h3 ? c2[0] : c2[1]);
+                            d1 += dpp_f32<0xB1>(d1); d2 += dpp_f32<0xB1>(d2);                           // quad_perm [1,0,3,2]
+                            d1 += dpp_f32<0x4E>(d1); d2 += dpp_f32<0x4E>(d2);                           // quad_perm [2,3,0,1]
+                            d1 += dpp_f32<0x141>(d1); d2 += dpp_f32<0x141>(d2);                         // row_half_mirror
                             const int it_l = (h5 ? 4 : 0) + (h4 ? 2 : 0) + (h3 ? 1 : 0);
                             const int sr_l = 16 * sw + 8 * hf + it_l;
                             const int row_l = (sr_l >> 5) * rstep + 32 * q + (sr_l & 31);
@@ -566,6 +607,10 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
                     asm volatile("" ::: "memory");
                 }
             }
+        }
+        if constexpr (LNF || STRIP) {
+            const unsigned sg = (unsigned)((g & 3) * STAGE);
+            MOCR_W2_READ_HEAD(P, offA + sg - hadj_nx, offB + sg);
         }
     }
 #undef MOCR_PERS_KTILE

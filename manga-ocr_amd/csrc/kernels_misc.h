@@ -131,3 +131,35 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         elem<TO>::st4(out + (size_t)row * D + c, o);
     }
 }
+
+// LayerNorm folded into the encoder GEMMs (gemm_pers_kernel LNF): what the fp32-residual GEMMs emit next to x for every
+// layer, for the rows the patch embedding wrote: x as bf16 (the next GEMM's A operand - x itself, not LN(x)) and the row's
+// (sum, sum of squares) in partial 0 of ln_part[row][4][2] (partials 1..3 zero).  One wave per row.
+template <int D>
+__global__ __launch_bounds__(256) void ln_prep_kernel(const float* __restrict__ x, bf16_t* __restrict__ xb, float* __restrict__ part, int M) {
+    static_assert(D % 256 == 0, "row = k * 64 lanes * 4");
+    constexpr int V = D / 256;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const float* xr = x + (size_t)row * D;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const int c = i * 256 + lane * 4;
+        const float4 t = *reinterpret_cast<const float4*>(xr + c);
+        uint2 u;
+        u.x = pack_bf16x2(t.x, t.y); u.y = pack_bf16x2(t.z, t.w);
+        *reinterpret_cast<uint2*>(xb + (size_t)row * D + c) = u;
+        s1 += (t.x + t.y) + (t.z + t.w);
+        s2 += fmaf(t.x, t.x, t.y * t.y) + fmaf(t.z, t.z, t.w * t.w);
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (lane < 2) {
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane == 0) { o.x = s1; o.y = s2; }
+        *reinterpret_cast<float4*>(part + (size_t)row * 8 + 4 * lane) = o;
+    }
+}
+

@@ -14,6 +14,7 @@ MOCR_F32, MOCR_BF16 = 0, 1
 FLAG_SIMPLE_ATTENTION, FLAG_NO_GRAPH, FLAG_NO_EARLY_EXIT, FLAG_CLASSIC_ATTENTION = 1, 2, 4, 8
 FLAG_NO_FUSED_ARGMAX, FLAG_NO_FUSED_QQT, FLAG_LATENT_ALWAYS, FLAG_FP8_ATTENTION = 16, 32, 64, 128
 FLAG_NO_SMALL_BATCH_PATH = 256
+FLAG_NO_LN_FOLD = 512
 EPI_SLAB, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_PATCH, EPI_BIAS_F32 = range(6)
 
 
@@ -67,6 +68,8 @@ SYMBOLS = {
     "mocr_recognize_gray_host": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P]),
     "mocr_op_gemm": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "mocr_op_layernorm": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32]),
+    "mocr_op_gemm_ln": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
+    "mocr_op_ln_prep": (C.c_int, [_P, _P, _P, _P, C.c_int32]),
     "mocr_op_enc_attention": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32]),
     "mocr_op_latent_attention": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int64]),
     "mocr_op_quant_fp8": (C.c_int, [_P, _P, _P, C.c_int64, C.c_float]),

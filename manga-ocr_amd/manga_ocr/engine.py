@@ -207,6 +207,14 @@ class Engine:
         self._check(self.lib.mocr_op_gemm(self._h, _ptr(dA), _ptr(dW), _ptr(d_bias), _ptr(d_out), _ptr(d_resid),
                                           M, N, K, epilogue, tile, split_k))
 
+    def op_gemm_ln(self, dA, dW, d_bias, d_out, d_resid, M, N, K, epilogue, tile, d_part, d_csum, d_xb) -> None:
+        """The persistent encoder GEMM with the LayerNorm folded in (include/mocr.h, mocr_op_gemm_ln)."""
+        self._check(self.lib.mocr_op_gemm_ln(self._h, _ptr(dA), _ptr(dW), _ptr(d_bias), _ptr(d_out), _ptr(d_resid), M, N, K, epilogue, tile,
+                                             _ptr(d_part), _ptr(d_csum), _ptr(d_xb)))
+
+    def op_ln_prep(self, d_x, d_xb, d_part, M) -> None:
+        self._check(self.lib.mocr_op_ln_prep(self._h, _ptr(d_x), _ptr(d_xb), _ptr(d_part), M))
+
     def op_layernorm(self, d_x, d_gamma, d_beta, d_out, M) -> None:
         self._check(self.lib.mocr_op_layernorm(self._h, _ptr(d_x), _ptr(d_gamma), _ptr(d_beta), _ptr(d_out), M))
 

@@ -177,3 +177,32 @@ def test_bf16_auto_path_teacher_forced_logits(gold, rows):
     assert np.isfinite(got).all() and d.max() <= BF16_LOGIT_TOL
     assert (gap[~agree] < BF16_LOGIT_TOL).all(), "argmax differs where the reference's margin exceeds the logit tolerance"
     assert agree.mean() >= 0.97
+
+
+def test_bf16_encoder_with_folded_layernorm_against_separate_launches_and_the_reference():
+    """From two 256 x 256 tiles per CU (~222 crops) the encoder's layer GEMMs run on the persistent kernel and the 24
+    LayerNorms between them are folded into those GEMMs (A = the residual rows themselves as bf16, statistics applied in the
+    epilogue; MOCR_FLAG_NO_LN_FOLD = 512 keeps them as launches).  Both forms against the fp32 oracle on the first crops, and
+    against each other on all 256: the fold must not cost accuracy."""
+    rows = 256
+    gray = crops(777, rows)
+    fold = engine("bf16", max_batch=rows)
+    plain = engine("bf16", max_batch=rows, flags=512)
+    dg = torch.from_numpy(gray).cuda()
+    torch.cuda.synchronize()
+    a = fold.encode(dg, rows).astype(np.float64)
+    b = plain.encode(dg, rows).astype(np.float64)
+    o = oracle()
+    ref = o.encode(o.preprocess_gray(gray[:6])).numpy().astype(np.float64)
+    scale = np.abs(ref).max()
+    e_a = np.abs(a[:6] - ref).max() / scale
+    e_b = np.abs(b[:6] - ref).max() / scale
+    rms_a = np.sqrt(((a[:6] - ref) ** 2).mean()) / scale
+    rms_b = np.sqrt(((b[:6] - ref) ** 2).mean()) / scale
+    d_ab = np.abs(a - b).max() / scale
+    report(f"bf16 encoder, {rows} crops: folded LayerNorm vs oracle max {e_a:.3e} rms {rms_a:.3e}; separate launches max {e_b:.3e} rms {rms_b:.3e}; "
+           f"fold vs separate max {d_ab:.3e}")
+    assert np.isfinite(a).all() and np.isfinite(b).all()
+    assert not np.array_equal(a, b), "the flag did not change the path"
+    assert e_a <= max(1.5 * e_b, 2e-2) and rms_a <= 1.3 * rms_b
+

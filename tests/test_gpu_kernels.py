@@ -170,6 +170,103 @@ def test_gemm_persistent_strip_schedule(tile, M, N, K):
     report(f"persistent gemm, strips, tile{tile} M{M} N{N} K{K}: max rel err {err:.3e} (tol 1.0e-05)")
 
 
+def _ln_stats_ref(x64):
+    """[M, D] float64 -> partial layout of one 256-column slice per slot: [M, 4, 2] (sum, sum of squares)."""
+    M, D = x64.shape
+    part = np.zeros((M, 4, 2))
+    for t in range(D // 256):
+        seg = x64[:, 256 * t:256 * (t + 1)]
+        part[:, t, 0] = seg.sum(1)
+        part[:, t, 1] = (seg * seg).sum(1)
+    return part
+
+
+@pytest.mark.parametrize("tile,M,K", [(4096, 33000, 768), (4099, 50432, 768), (4099, 33000, 3072), (4100, 2200, 768), (4097, 2500, 3072)])
+def test_gemm_persistent_residual_emits_ln_operands(tile, M, K):
+    """LayerNorm folded into the encoder GEMMs, producer side (gemm_pers_kernel LNF, EPI_BIAS_RESID; tile list and strips):
+    next to out = resid + A W^T + b the kernel writes the rows as bf16 and each row's (sum, sum of squares) per 256-column
+    slice - what the GEMM behind the LayerNorm needs instead of LN(out)."""
+    eng = engine("bf16")
+    N = 768
+    rs = np.random.RandomState(M + K + tile)
+    Mp = (M + 255) // 256 * 256
+    A = bf16_round(rs.standard_normal((Mp, K)).astype(np.float32))
+    W = bf16_round((rs.standard_normal((N, K)) * 0.05).astype(np.float32))
+    bias = rs.standard_normal(N).astype(np.float32)
+    resid = (rs.standard_normal((M, N)) * 2.0 + rs.standard_normal((M, 1))).astype(np.float32)      # rows with a mean of their own
+    ref = A[:M].astype(np.float64) @ W.astype(np.float64).T + bias + resid
+    dA, dW, dB = _dev(A, "bf16"), _dev(W, "bf16"), torch.from_numpy(bias).cuda()
+    dO = torch.full((M + 3, N), float("nan"), device="cuda", dtype=torch.float32)
+    dO[:M] = torch.from_numpy(resid).cuda()
+    dXb = torch.full((M + 3, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+    dP = torch.full((M + 3, 4, 2), -7.0, device="cuda", dtype=torch.float32)
+    torch.cuda.synchronize()
+    eng.op_gemm_ln(dA, dW, dB, dO, dO, M, N, K, EPI_BIAS_RESID, tile, dP, None, dXb)
+    got = dO.cpu().numpy().astype(np.float64)
+    assert np.isnan(got[M:]).all(), "rows behind M were written"
+    err = np.abs(got[:M] - ref).max() / np.abs(ref).max()
+    assert err <= 1e-5, f"out: max rel err {err:.3e}"
+    xb = dXb.float().cpu().numpy()
+    assert np.isnan(xb[M:]).all()
+    assert np.array_equal(xb[:M], bf16_round(got[:M].astype(np.float32))), "the bf16 copy is not the rounded fp32 output"
+    part = dP.cpu().numpy().astype(np.float64)
+    assert (part[M:] == -7.0).all() and (part[:M, 3] == -7.0).all(), "statistics written outside rows < M / slices 0..2"
+    want = _ln_stats_ref(got[:M])
+    perr = np.abs(part[:M, :3] - want[:, :3]).max(axis=(0, 1)) / np.abs(want[:, :3]).max(axis=(0, 1))
+    report(f"persistent gemm + LN operands tile{tile} M{M} K{K}: out {err:.2e}, sums {perr[0]:.2e}, squares {perr[1]:.2e}")
+    assert perr.max() <= 2e-6
+
+
+@pytest.mark.parametrize("epi", [EPI_BIAS, EPI_BIAS_GELU])
+@pytest.mark.parametrize("tile,M,N", [(4096, 8900, 2304), (4097, 2500, 3072), (4096, 50432, 2304)])
+def test_gemm_persistent_with_folded_layernorm(epi, tile, M, N):
+    """Consumer side (EPI_BIAS / EPI_BIAS_GELU with LNF): A = bf16 x, W = bf16(W o gamma), bias = b + W beta, column sums and the
+    rows' statistics -> LN(x) W^T + b.  Checked (a) against the identity evaluated in float64 on the operands the kernel
+    was given (bf16 output rounding only) and (b) against the real thing, LN(x) in float64 times the unrounded weight."""
+    eng = engine("bf16")
+    K = 768
+    rs = np.random.RandomState(M + N + epi)
+    x = (rs.standard_normal((M, K)) * (0.5 + rs.rand(M, 1) * 3) + rs.standard_normal((M, 1)) * 0.7).astype(np.float32)
+    x[:, 5] *= 8.0                                                     # an outlier channel
+    g = (1.0 + 0.2 * rs.standard_normal(K)).astype(np.float32)
+    be = (0.1 * rs.standard_normal(K)).astype(np.float32)
+    W = (rs.standard_normal((N, K)) * 0.05).astype(np.float32)
+    b = rs.standard_normal(N).astype(np.float32)
+    Wf = bf16_round(W * g)
+    csum = Wf.astype(np.float64).sum(1).astype(np.float32)
+    bf = (b.astype(np.float64) + W.astype(np.float64) @ be.astype(np.float64)).astype(np.float32)
+    x64 = x.astype(np.float64)
+    mean = x64.mean(1, keepdims=True)
+    var = ((x64 - mean) ** 2).mean(1, keepdims=True)
+    rstd = 1.0 / np.sqrt(var + 1e-12)
+    real = ((x64 - mean) * rstd * g + be) @ W.astype(np.float64).T + b
+    xb = bf16_round(x)
+    ident = rstd * (xb.astype(np.float64) @ Wf.astype(np.float64).T - mean * csum.astype(np.float64)) + bf
+    if epi == EPI_BIAS_GELU:
+        real, ident = _gelu(real), _gelu(ident)
+    Mp = (M + 255) // 256 * 256
+    dX = torch.from_numpy(x).cuda()
+    dXb = torch.zeros((Mp, K), device="cuda", dtype=torch.bfloat16)
+    dP = torch.zeros((Mp, 4, 2), device="cuda", dtype=torch.float32)
+    eng.op_ln_prep(dX, dXb, dP, M)
+    assert np.array_equal(dXb[:M].float().cpu().numpy(), xb)
+    part = dP[:M].cpu().numpy().astype(np.float64)
+    assert np.abs(part[:, 0, 0] - x64.sum(1)).max() <= 2e-6 * np.abs(x64).sum(1).max() and (part[:, 1:] == 0).all()
+    # spread the sums over three slots, as the fp32-residual GEMM writes them (the consumer adds the four slots up)
+    want = _ln_stats_ref(x64)
+    dP[:M] = torch.from_numpy(want.astype(np.float32)).cuda()
+    dW, dB, dC = _dev(Wf, "bf16"), torch.from_numpy(bf).cuda(), torch.from_numpy(csum).cuda()
+    dO = torch.full((M + 3, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+    torch.cuda.synchronize()
+    eng.op_gemm_ln(dXb, dW, dB, dO, None, M, N, K, epi, tile, dP, dC, None)
+    got = dO.float().cpu().numpy().astype(np.float64)
+    assert np.isnan(got[M:]).all(), "rows behind M were written"
+    e_ident = np.abs(got[:M] - ident).max() / np.abs(ident).max()
+    e_real = np.abs(got[:M] - real).max() / np.abs(real).max()
+    report(f"persistent gemm with folded LN tile{tile} M{M} N{N} epi{epi}: vs identity {e_ident:.3e} (tol 6e-3), vs LN(x) W^T {e_real:.3e} (tol 2e-2)")
+    assert np.isfinite(got[:M]).all() and e_ident <= 6e-3 and e_real <= 2e-2
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("M,N,K,split", [(64, 768, 768, 12), (37, 2304, 768, 4), (128, 768, 3072, 16), (64, 6144, 768, 2)])
 def test_gemm_split_k_slabs(dtype, M, N, K, split):

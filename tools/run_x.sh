@@ -1,6 +1,17 @@
 #!/bin/bash
 set -o pipefail
-export MOCR_LIB=manga-ocr_amd/manga_ocr/_lib/libmocr_hip_lab.so
-for i in 1 2; do
-timeout -k 10 300 python tools/gemm_bench.py enc 50432 t4 2>&1 | grep -E "oproj|fc2" | grep -E "t4096|t4099|t4103"
-done
+O=gpurun_out/r3n
+mkdir -p $O
+timeout -k 10 600 python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "folded_layernorm" > $O/pytest.txt 2>&1; rc=$?; echo "pytest rc=$rc"; tail -3 $O/pytest.txt
+[ $rc -ne 0 ] && exit $rc
+run() { name=$1; shift; timeout -k 10 300 python bench.py --no-cpu-baseline --no-config4 --no-parity-leg --steps 10 "$@" > $O/$name.json 2> $O/$name.err; python - <<PY
+import json
+d=json.load(open("$O/$name.json"))
+e=d.get("encoder_only") or {}
+print("$name", "value", round(d["value"]), "enc", round(e.get("kernel_ms",0),2), round(e.get("frac_of_mfma_peak",0),4), [(k[0][5:],k[2]) for k in e.get("kernels")][:8])
+PY
+}
+run fold
+run nofold --engine-flags 512
+run fold2
+run nofold2 --engine-flags 512
