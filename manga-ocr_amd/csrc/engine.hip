@@ -418,6 +418,8 @@ void launch_gemm_pers_t(mocr_engine* e, const GemmParams& p0, int blocks) {
     grid = std::max(8, grid / 8 * 8);
     static const int stagger_env = env_int("MOCR_GEMM_STAGGER", 0);
     p.stagger = stagger_env;
+    static const int hpos_env = env_int("MOCR_GEMM_HPOS", 0);
+    p.first_round = hpos_env;
     hipLaunchKernelGGL((gemm_pers_kernel<EPI, SPLIT_DMA, PAIR, STRIP, LNF>), dim3(grid), dim3(512), PERS_LDS, e->stream, p);
     HIPCHECK(hipGetLastError());
 }
@@ -431,25 +433,32 @@ void launch_gemm_pers(mocr_engine* e, const GemmParams& p, int epi, int blocks, 
     if (lnf && !(SPLIT_DMA && (epi == EPI_BIAS_RESID ? (PAIR && p.N <= 1024 && p.xb) : (!PAIR && p.csum))))
         throw ArgError{"persistent gemm: LayerNorm folding needs the product kernel forms and their operands", MOCR_ERR_ARG};
     if constexpr (SPLIT_DMA) {
-        if (epi == EPI_BIAS_RESID && strip) {
+        bool strips = false;
+        if (strip) {
             const int ntn = p.N / 256, ntiles = ((p.M + 255) / 256) * ntn;
             const int grid = std::max(8, std::min(blocks > 0 ? blocks : e->num_cus, (ntiles + 7) / 8 * 8) / 8 * 8);
-            if (strip > 0 ? pers_strip_rows(p.M, ntn, grid) > 0 : pers_strip_wins(p.M, ntn, grid)) {
-                if constexpr (PAIR) {
-                    if (lnf) { launch_gemm_pers_t<EPI_BIAS_RESID, true, true, true, true>(e, p, blocks); return; }
-                }
-                launch_gemm_pers_t<EPI_BIAS_RESID, true, PAIR, true>(e, p, blocks);
-                return;
+            strips = strip > 0 ? pers_strip_rows(p.M, ntn, grid) > 0 : pers_strip_wins(p.M, ntn, grid);
+        }
+        if constexpr (PAIR) {
+            if (epi == EPI_BIAS_RESID) {
+                if (strips && lnf) { launch_gemm_pers_t<EPI_BIAS_RESID, true, true, true, true>(e, p, blocks); return; }
+                if (strips) { launch_gemm_pers_t<EPI_BIAS_RESID, true, true, true>(e, p, blocks); return; }
+                if (lnf) { launch_gemm_pers_t<EPI_BIAS_RESID, true, true, false, true>(e, p, blocks); return; }
+            }
+        } else {
+            if (epi == EPI_BIAS_RESID && strips) { launch_gemm_pers_t<EPI_BIAS_RESID, true, false, true>(e, p, blocks); return; }
+            if (epi == EPI_BIAS_GELU) {
+                if (strips && lnf) { launch_gemm_pers_t<EPI_BIAS_GELU, true, false, true, true>(e, p, blocks); return; }
+                if (strips) { launch_gemm_pers_t<EPI_BIAS_GELU, true, false, true>(e, p, blocks); return; }
+                if (lnf) { launch_gemm_pers_t<EPI_BIAS_GELU, true, false, false, true>(e, p, blocks); return; }
+            }
+            if (epi == EPI_BIAS) {
+                if (strips && lnf) { launch_gemm_pers_t<EPI_BIAS, true, false, true, true>(e, p, blocks); return; }
+                if (strips) { launch_gemm_pers_t<EPI_BIAS, true, false, true>(e, p, blocks); return; }
+                if (lnf) { launch_gemm_pers_t<EPI_BIAS, true, false, false, true>(e, p, blocks); return; }
             }
         }
-        if (lnf) {
-            if constexpr (PAIR) { launch_gemm_pers_t<EPI_BIAS_RESID, true, true, false, true>(e, p, blocks); return; }
-            else {
-                if (epi == EPI_BIAS) launch_gemm_pers_t<EPI_BIAS, true, false, false, true>(e, p, blocks);
-                else launch_gemm_pers_t<EPI_BIAS_GELU, true, false, false, true>(e, p, blocks);
-                return;
-            }
-        }
+        if (lnf) throw ArgError{"persistent gemm: no LayerNorm-folding form of this kernel variant", MOCR_ERR_ARG};
     }
     switch (epi) {
         case EPI_BIAS: launch_gemm_pers_t<EPI_BIAS, SPLIT_DMA, PAIR>(e, p, blocks); break;
@@ -529,7 +538,7 @@ void gemm(mocr_engine* e, const char* name, const void* A, int lda, const void* 
         static const int strip_env = env_int("MOCR_GEMM_STRIP", -1);     // -1: strips where they walk fewer rounds (r03, M = 50,432: O-proj 133 -> 113 us, FC2 303 -> 275)
         const int strip = tile >= 4099 ? 1 : tile == 4097 ? 0 : strip_env;
         if (epi == EPI_BIAS_RESID) launch_gemm_pers<true, true>(e, p, epi, blocks, strip);
-        else launch_gemm_pers<true, false>(e, p, epi, blocks);
+        else launch_gemm_pers<true, false>(e, p, epi, blocks, strip);
     }
 #ifdef MOCR_EXPERIMENTS
     else if (tile == 4098) launch_gemm_pers<false>(e, p, epi, 0);   // experiment: every wave requests LDS-DMA
@@ -1160,8 +1169,12 @@ template <typename T> void init_kernel_attrs() {
     set_max_lds(gemm_pers_kernel<EPI_BIAS_RESID, true, true, false, true>, PERS_LDS);
     set_max_lds(gemm_pers_kernel<EPI_BIAS, true, false, false, true>, PERS_LDS);
     set_max_lds(gemm_pers_kernel<EPI_BIAS_GELU, true, false, false, true>, PERS_LDS);
-#ifdef MOCR_EXPERIMENTS
+    set_max_lds(gemm_pers_kernel<EPI_BIAS, true, false, true, true>, PERS_LDS);
+    set_max_lds(gemm_pers_kernel<EPI_BIAS_GELU, true, false, true, true>, PERS_LDS);
+    set_max_lds(gemm_pers_kernel<EPI_BIAS, true, false, true>, PERS_LDS);
+    set_max_lds(gemm_pers_kernel<EPI_BIAS_GELU, true, false, true>, PERS_LDS);
     set_max_lds(gemm_pers_kernel<EPI_BIAS_RESID, true, false, true>, PERS_LDS);
+#ifdef MOCR_EXPERIMENTS
     set_max_lds(gemm_pers_kernel<EPI_BIAS, true, true>, PERS_LDS);
     set_max_lds(gemm_pers_kernel<EPI_BIAS_GELU, true, true>, PERS_LDS);
     set_max_lds(gemm_pers_kernel<EPI_BIAS, false>, PERS_LDS);

@@ -117,7 +117,12 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
                 s_rem = R & 255;
                 tile_end = (R >> 8) + (s_rem ? 1 : 0);
                 if (s_rem && s_rem <= 128) {
-                    const int v = strip % 3;
+#ifdef MOCR_EXPERIMENTS
+                    const int hmode = p.first_round;      // MOCR_GEMM_HPOS: 0 by thirds (last / first / middle), 1 by halves (last / first), 2 all last, 3 all first
+#else
+                    constexpr int hmode = 0;
+#endif
+                    const int v = hmode == 0 ? strip % 3 : hmode == 1 ? strip % 2 : hmode == 2 ? 0 : 1;
                     s_hpos = v == 0 ? tile_end - 1 : v == 1 ? 0 : tile_end >> 1;
                 }
                 s_n0 = col * BN;
@@ -433,7 +438,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
                 asm volatile("" ::: "memory");
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    const float2 mr = *reinterpret_cast<const float2*>(sst + 2 * (wm * 128 + 16 * i + l15));
+                    const float2 mr = *reinterpret_cast<const float2*>(sst + 2 * (wm * (STRIP && half ? 64 : 128) + 16 * i + l15));
                     mu[i] = mr.x; rs[i] = mr.y;
                 }
 #pragma unroll
@@ -452,6 +457,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
             // 16-byte chunk c of staging row sr at chunk c ^ (sr & 15)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
+                if (STRIP && h == 1 && half) continue;      // a half tile's wave holds m-tiles 0..3 only (window rows 64 wm + 16 i)
 #pragma unroll
                 for (int ii = 0; ii < 4; ++ii) {
                     const int i = 4 * h + ii;
@@ -500,9 +506,10 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
 #pragma unroll
                         for (int it = 0; it < 8; ++it) {
                             const int sr = 32 * sw + 16 * hf + 2 * it + rsel;
-                            const int row = (sr >> 6) * 128 + 64 * h + (sr & 63);
+                            const int row = (sr >> 6) * (STRIP && half ? 64 : 128) + 64 * h + (sr & 63);
+                            const bool mine = STRIP ? (unsigned)row - own_lo < own_n : (!guard || m0 + row < p.M);
                             // non-temporal: the QKV / FC1 output passes through once (r02: +4 % on the encoder)
-                            if ((!guard || m0 + row < p.M) && !(ablate & 8)) st16_nt(obase + (size_t)row * ldo, v[it]);
+                            if (mine && !(ablate & 8)) st16_nt(obase + (size_t)row * ldo, v[it]);
                         }
                     }
                 } else {

@@ -170,6 +170,31 @@ def test_gemm_persistent_strip_schedule(tile, M, N, K):
     report(f"persistent gemm, strips, tile{tile} M{M} N{N} K{K}: max rel err {err:.3e} (tol 1.0e-05)")
 
 
+@pytest.mark.parametrize("epi", [EPI_BIAS, EPI_BIAS_GELU])
+@pytest.mark.parametrize("tile,M,N,K", [(4099, 50432, 3072, 768), (4099, 33000, 2304, 768), (4100, 2200, 768, 128), (4100, 1000, 1024, 256), (4100, 300, 768, 256)])
+def test_gemm_persistent_strip_schedule_bf16_outputs(epi, tile, M, N, K):
+    """The strip schedule with the bf16 epilogues (FC1 at batch 256: 9.23 rounds of tiles walked as 9 tiles + a half tile):
+    a half tile is staged and stored in ONE pass of 128 rows."""
+    eng = engine("bf16")
+    rs = np.random.RandomState(M + N + K + epi + tile)
+    A = bf16_round(rs.standard_normal((M, K)).astype(np.float32))          # not padded: strips read no row behind M
+    W = bf16_round((rs.standard_normal((N, K)) * 0.05).astype(np.float32))
+    bias = rs.standard_normal(N).astype(np.float32)
+    ref = A.astype(np.float64) @ W.astype(np.float64).T + bias
+    if epi == EPI_BIAS_GELU:
+        ref = _gelu(ref)
+    dA, dW, dB = _dev(A, "bf16"), _dev(W, "bf16"), torch.from_numpy(bias).cuda()
+    dO = torch.full((M + 3, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+    torch.cuda.synchronize()
+    for rep in range(2):
+        eng.op_gemm(dA, dW, dB, dO, None, M, N, K, epi, tile=tile, split_k=1)
+        got = dO.float().cpu().numpy().astype(np.float64)
+        assert np.isnan(got[M:]).all(), "rows behind M were written"
+        err = np.abs(got[:M] - ref).max() / np.abs(ref).max()
+        assert np.isfinite(got[:M]).all() and err <= 6e-3, f"rep {rep}: max rel err {err:.3e}"
+    report(f"persistent gemm, strips, tile{tile} M{M} N{N} K{K} epi{epi}: max rel err {err:.3e} (tol 6.0e-03)")
+
+
 def _ln_stats_ref(x64):
     """[M, D] float64 -> partial layout of one 256-column slice per slot: [M, 4, 2] (sum, sum of squares)."""
     M, D = x64.shape
@@ -218,7 +243,7 @@ def test_gemm_persistent_residual_emits_ln_operands(tile, M, K):
 
 
 @pytest.mark.parametrize("epi", [EPI_BIAS, EPI_BIAS_GELU])
-@pytest.mark.parametrize("tile,M,N", [(4096, 8900, 2304), (4097, 2500, 3072), (4096, 50432, 2304)])
+@pytest.mark.parametrize("tile,M,N", [(4096, 8900, 2304), (4097, 2500, 3072), (4096, 50432, 2304), (4099, 50432, 3072), (4100, 2200, 768)])
 def test_gemm_persistent_with_folded_layernorm(epi, tile, M, N):
     """Consumer side (EPI_BIAS / EPI_BIAS_GELU with LNF): A = bf16 x, W = bf16(W o gamma), bias = b + W beta, column sums and the
     rows' statistics -> LN(x) W^T + b.  Checked (a) against the identity evaluated in float64 on the operands the kernel

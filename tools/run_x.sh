@@ -1,17 +1,7 @@
 #!/bin/bash
+# final r03 numbers: the bench lines kept under profiles/ and the three rocprofv3 passes
 set -o pipefail
-O=gpurun_out/r3n
-mkdir -p $O
-timeout -k 10 600 python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "folded_layernorm" > $O/pytest.txt 2>&1; rc=$?; echo "pytest rc=$rc"; tail -3 $O/pytest.txt
-[ $rc -ne 0 ] && exit $rc
-run() { name=$1; shift; timeout -k 10 300 python bench.py --no-cpu-baseline --no-config4 --no-parity-leg --steps 10 "$@" > $O/$name.json 2> $O/$name.err; python - <<PY
-import json
-d=json.load(open("$O/$name.json"))
-e=d.get("encoder_only") or {}
-print("$name", "value", round(d["value"]), "enc", round(e.get("kernel_ms",0),2), round(e.get("frac_of_mfma_peak",0),4), [(k[0][5:],k[2]) for k in e.get("kernels")][:8])
-PY
-}
-run fold
-run nofold --engine-flags 512
-run fold2
-run nofold2 --engine-flags 512
+cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
+bash tools/run_final.sh
+bash tools/profile_passes.sh gpurun_out/prof_r03 > gpurun_out/prof_r03.log 2>&1; echo "profile rc=$?"
+tail -3 gpurun_out/prof_r03.log

@@ -31,7 +31,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLASSES = [  # (substring of the kernel symbol, bench.py's class name)
     ("latent_attn_kernel<true>", "lat_attn_self"), ("latent_attn_kernel<false>", "lat_attn_cross"),
     ("latent_attn_fp8_kernel<true>", "lat8_attn_self"), ("latent_attn_fp8_kernel<false>", "lat8_attn_cross"),
-    ("dec_qqt_kernel", "dec_qqt"), ("enc_attn_mfma_kernel", "enc_attn_mfma"), ("layernorm_kernel", "layernorm"),
+    ("dec_qqt_kernel", "dec_qqt"), ("enc_attn_mfma_kernel", "enc_attn_mfma"), ("enc_attn2_kernel", "enc_attn_mfma"),
+    ("layernorm_kernel", "layernorm"), ("ln_prep_kernel", "ln_prep"),
     ("dec_add_ln_kernel", "dec_add_ln"), ("dec_token_kernel", "dec_token"), ("gemm_wide2_kernel", "gemm_enc_layers(wide2)"),
     # the persistent encoder GEMM by epilogue: <1 = bias (QKV), <2 = bias + GELU (FC1), <3 = bias + fp32 residual (O-proj and FC2)
     ("gemm_pers_kernel<1", "gemm_enc_qkv"), ("gemm_pers_kernel<2", "gemm_enc_fc1"), ("gemm_pers_kernel<3", "gemm_enc_oproj+fc2"),
@@ -76,8 +77,8 @@ def algorithmic_bytes(c, rows, max_len=300):
         return (M * 768 + 2304 * 768) * 2 + M * 2304 * 2
     if c == "gemm_enc_fc1":
         return (M * 768 + 3072 * 768) * 2 + M * 3072 * 2
-    if c == "gemm_enc_oproj+fc2":  # equal launch counts: the mean of the two
-        return ((M * 768 + 768 * 768) * 2 + (M * 3072 + 768 * 3072) * 2) / 2 + 2 * M * 768 * 4
+    if c == "gemm_enc_oproj+fc2":  # equal launch counts: the mean of the two; + the bf16 copy of the rows (LayerNorm folding, r03)
+        return ((M * 768 + 768 * 768) * 2 + (M * 3072 + 768 * 3072) * 2) / 2 + 2 * M * 768 * 4 + M * 768 * 2
     return None
 
 
