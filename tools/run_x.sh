@@ -1,7 +1,16 @@
 #!/bin/bash
-# final r03 numbers: the bench lines kept under profiles/ and the three rocprofv3 passes
 set -o pipefail
-cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-bash tools/run_final.sh
-bash tools/profile_passes.sh gpurun_out/prof_r03 > gpurun_out/prof_r03.log 2>&1; echo "profile rc=$?"
-tail -3 gpurun_out/prof_r03.log
+O=gpurun_out/r3q
+mkdir -p $O
+MOCR_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29511 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 timeout -k 10 300 python bench.py --gpus 1 --steps 8 --warmup 2 --no-cpu-baseline --no-config4 --no-parity-leg --no-profile > $O/dist_weak.json 2> $O/dist_weak.err; echo "weak rc=$?"
+MOCR_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29512 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 timeout -k 10 300 python bench.py --gpus 1 --queue 2000 --no-cpu-baseline --no-config4 --no-parity-leg --no-profile > $O/dist_queue.json 2> $O/dist_queue.err; echo "queue rc=$?"
+timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29513 bench.py --gpus 1 --steps 8 --warmup 2 --no-cpu-baseline --no-config4 --no-parity-leg --no-profile > $O/torchrun.json 2> $O/torchrun.err; echo "torchrun rc=$?"
+python - <<'PY'
+import json
+for n in ("dist_weak","dist_queue","torchrun"):
+    try:
+        d=json.loads(open(f"gpurun_out/r3q/{n}.json").read().strip().splitlines()[-1])
+        print(n, round(d["value"]), d.get("scaling"), d.get("rccl_world_size"), d["n_gpus"])
+    except Exception as ex: print(n, "ERR", ex)
+PY
+tail -3 $O/torchrun.err
