@@ -369,8 +369,24 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
                 bias[j][0] = bv.x; bias[j][1] = bv.y; bias[j][2] = bv.z; bias[j][3] = bv.w;
             }
         }
+        // LNF, the GEMM behind a LayerNorm: the store waves put what they requested above into the spare 32 KiB (free between
+        // epilogues) in front of the tile's LAST pair of K-tiles - [256] (mean, rstd) of the tile's rows, then [256] (column
+        // sum, bias) of its columns; the barriers of that pair publish it, the epilogue only reads
+        auto ln_handover = [&]() {
+            if constexpr (LNF && EPI != EPI_BIAS_RESID) {
+                if (!dma_wave) {
+                    float* const sst = reinterpret_cast<float*>(smem + RING);
+                    const float inv_k = 1.0f / (float)p.k_per_split;
+                    const float mean = ((st_a.x + st_a.z) + (st_b.x + st_b.z)) * inv_k;
+                    const float var = fmaxf(((st_a.y + st_a.w) + (st_b.y + st_b.w)) * inv_k - mean * mean, 0.f);
+                    *reinterpret_cast<float2*>(sst + 2 * (64 * sw + lane)) = make_float2(mean, 1.0f / sqrtf(var + p.ln_eps));
+                    *reinterpret_cast<float2*>(sst + 512 + 2 * (64 * sw + lane)) = make_float2(cs_l, bias_l);
+                }
+            }
+        };
         if constexpr (STRIP) {
             for (int t = 0; t < nt; t += 2) {
+                if (t + 2 >= nt) ln_handover();
                 const unsigned hadj_h = t + 2 < nt ? hadj : hadj_nx;      // the tile of the K-tile behind this pair
                 if constexpr (PAIR) {
                     MOCR_PERS_KTILE_A(P, Q)
@@ -389,6 +405,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
         } else {
             constexpr unsigned hadj_k = 0;
             for (int t = 0; t < nt; t += 2) {
+                if (t + 2 >= nt) ln_handover();
                 MOCR_PERS_KTILE(P, Q)
                 MOCR_PERS_KTILE(Q, P)
             }
@@ -397,7 +414,8 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
         // LDS free right now: the slot of the K-tile just multiplied, (g - 1) & 3 (every wave passed that K-tile's barrier
         // with all its fragments in registers), and the spare 32 KiB.  K-tiles g, g + 1, g + 2 of the NEXT tile sit in the
         // other three slots (landed / in flight); P holds the first six fragments of K-tile g already.
-        if constexpr (LNF || STRIP) {
+        const bool give_up_p = LNF || STRIP || (ablate & 4096);      // (4096: diagnostics - the plain kernel pays the re-request too)
+        if (give_up_p) {
             // The LayerNorm-folding epilogues need ~30 registers more than the plain ones (the strip schedule a few), and a spill in this kernel is a
             // scratch LOAD in a DMA wave's queue: its wait drains the ring.  The first six fragments of the next K-tile (24
             // registers, requested by the last K-tile) are given up here and requested again behind the epilogue.
@@ -423,19 +441,16 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
         if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
             [[maybe_unused]] float cs[4][4], mu[8], rs[8];
             if constexpr (LNF) {
-                // through the spare 32 KiB (free until the first staging write): [256] (mean, rstd) of the tile's rows, then
-                // [256] (column sum, bias) of its columns
+                // handed over by the store waves in front of the last pair of K-tiles (ln_handover)
                 float* const sst = reinterpret_cast<float*>(piece0);
-                if (!dma_wave) {
-                    const float inv_k = 1.0f / (float)p.k_per_split;
-                    const float mean = ((st_a.x + st_a.z) + (st_b.x + st_b.z)) * inv_k;
-                    const float var = fmaxf(((st_a.y + st_a.w) + (st_b.y + st_b.w)) * inv_k - mean * mean, 0.f);
-                    *reinterpret_cast<float2*>(sst + 2 * (64 * sw + lane)) = make_float2(mean, 1.0f / sqrtf(var + p.ln_eps));
-                    *reinterpret_cast<float2*>(sst + 512 + 2 * (64 * sw + lane)) = make_float2(cs_l, bias_l);
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
+                if (ablate & 1024) {                       // diagnostics: no hand-over reads, no barrier
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { mu[i] = 0.25f; rs[i] = 1.5f; }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { cs[j][r] = 0.5f; bias[j][r] = 0.125f; }
+                } else {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const float2 mr = *reinterpret_cast<const float2*>(sst + 2 * (wm * (STRIP && half ? 64 : 128) + 16 * i + l15));
@@ -451,6 +466,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();                 // read: the staging passes may write the spare area
                 asm volatile("" ::: "memory");
+                }
             }
             // two passes of 128 rows x 512 B: pass h takes rows 64h .. 64h+63 of each wave's 128 (m-tiles 4h .. 4h+3);
             // staging row sr = 64 wm + (row within the 64): rows 0-63 in piece0, 64-127 in piece1;
@@ -468,7 +484,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
                         float v[4];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            if constexpr (LNF) v[r] = fmaf(rs[i], fmaf(-mu[i], cs[j][r], acc[j][i][r]), bias[j][r]);
+                            if constexpr (LNF) v[r] = (ablate & 2048) ? acc[j][i][r] + bias[j][r] : fmaf(rs[i], fmaf(-mu[i], cs[j][r], acc[j][i][r]), bias[j][r]);
                             else v[r] = acc[j][i][r] + bias[j][r];
                             if constexpr (EPI == EPI_BIAS_GELU) { if (!(ablate & 32)) v[r] = gelu_fast(v[r]); }
                             acc[j][i][r] = 0.f;
@@ -615,7 +631,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
                 }
             }
         }
-        if constexpr (LNF || STRIP) {
+        if (give_up_p) {
             const unsigned sg = (unsigned)((g & 3) * STAGE);
             MOCR_W2_READ_HEAD(P, offA + sg - hadj_nx, offB + sg);
         }
