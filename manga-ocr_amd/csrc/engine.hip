@@ -430,7 +430,7 @@ template <bool SPLIT_DMA, bool PAIR = false>
 void launch_gemm_pers(mocr_engine* e, const GemmParams& p, int epi, int blocks, int strip = 0) {
     if (p.k_per_split % 64 || p.k_per_split < 128) throw ArgError{"persistent gemm: K must be a multiple of 64, >= 128", MOCR_ERR_ARG};
     const bool lnf = p.ln_part != nullptr;
-    if (lnf && !(SPLIT_DMA && (epi == EPI_BIAS_RESID ? (PAIR && p.N <= 1024 && p.xb) : (!PAIR && p.csum))))
+    if (lnf && !(SPLIT_DMA && (epi == EPI_BIAS_RESID ? (PAIR && p.N <= 1024 && p.xb) : p.csum != nullptr)))
         throw ArgError{"persistent gemm: LayerNorm folding needs the product kernel forms and their operands", MOCR_ERR_ARG};
     if constexpr (SPLIT_DMA) {
         bool strips = false;
@@ -445,6 +445,9 @@ void launch_gemm_pers(mocr_engine* e, const GemmParams& p, int epi, int blocks, 
                 if (strips) { launch_gemm_pers_t<EPI_BIAS_RESID, true, true, true>(e, p, blocks); return; }
                 if (lnf) { launch_gemm_pers_t<EPI_BIAS_RESID, true, true, false, true>(e, p, blocks); return; }
             }
+            // the bf16 epilogues on the one-barrier-per-two-K-tiles loop (K64: 64-deep LDS image, whole-line DMA requests)
+            if (epi == EPI_BIAS_GELU && lnf) { launch_gemm_pers_t<EPI_BIAS_GELU, true, true, false, true>(e, p, blocks); return; }
+            if (epi == EPI_BIAS && lnf) { launch_gemm_pers_t<EPI_BIAS, true, true, false, true>(e, p, blocks); return; }
         } else {
             if (epi == EPI_BIAS_RESID && strips) { launch_gemm_pers_t<EPI_BIAS_RESID, true, false, true>(e, p, blocks); return; }
             if (epi == EPI_BIAS_GELU) {
@@ -537,7 +540,11 @@ void gemm(mocr_engine* e, const char* name, const void* A, int lda, const void* 
         const int blocks = (tile == 4097 || tile == 4100) ? 8 : 0;     // 4097: test hook, 8 blocks walk all the tiles
         static const int strip_env = env_int("MOCR_GEMM_STRIP", -1);     // -1: strips where they walk fewer rounds (r03, M = 50,432: O-proj 133 -> 113 us, FC2 303 -> 275)
         const int strip = tile >= 4099 ? 1 : tile == 4097 ? 0 : strip_env;
+        // the bf16-epilogue GEMMs: 1 = the one-barrier-per-two-K-tiles loop with the 64-deep LDS image (K64), 0 = one barrier per
+        // 32-deep K-tile, three K-tiles in flight (r03 first session's choice, when both loops fed on half-line requests)
+        static const int pair_bf16 = env_int("MOCR_GEMM_PAIR_BF16", 1);
         if (epi == EPI_BIAS_RESID) launch_gemm_pers<true, true>(e, p, epi, blocks, strip);
+        else if (pair_bf16 && !(strip > 0)) launch_gemm_pers<true, true>(e, p, epi, blocks, 0);
         else launch_gemm_pers<true, false>(e, p, epi, blocks, strip);
     }
 #ifdef MOCR_EXPERIMENTS
@@ -1174,9 +1181,11 @@ template <typename T> void init_kernel_attrs() {
     set_max_lds(gemm_pers_kernel<EPI_BIAS, true, false, true>, PERS_LDS);
     set_max_lds(gemm_pers_kernel<EPI_BIAS_GELU, true, false, true>, PERS_LDS);
     set_max_lds(gemm_pers_kernel<EPI_BIAS_RESID, true, false, true>, PERS_LDS);
-#ifdef MOCR_EXPERIMENTS
     set_max_lds(gemm_pers_kernel<EPI_BIAS, true, true>, PERS_LDS);
     set_max_lds(gemm_pers_kernel<EPI_BIAS_GELU, true, true>, PERS_LDS);
+    set_max_lds(gemm_pers_kernel<EPI_BIAS, true, true, false, true>, PERS_LDS);
+    set_max_lds(gemm_pers_kernel<EPI_BIAS_GELU, true, true, false, true>, PERS_LDS);
+#ifdef MOCR_EXPERIMENTS
     set_max_lds(gemm_pers_kernel<EPI_BIAS, false>, PERS_LDS);
     set_max_lds(gemm_pers_kernel<EPI_BIAS_GELU, false>, PERS_LDS);
     set_max_lds(gemm_pers_kernel<EPI_BIAS_RESID, false>, PERS_LDS);

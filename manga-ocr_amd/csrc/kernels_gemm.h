@@ -415,6 +415,19 @@ struct WideFrags { bf16x8 fb[4]; bf16x8 fa[8]; };
                  : "=&v"(F.fa[2]), "=&v"(F.fa[3]), "=&v"(F.fa[4]), "=&v"(F.fa[5]), "=&v"(F.fa[6]), "=&v"(F.fa[7])       \
                  : "v"(aA)                                                                                               \
                  : "memory")
+// the same reads from the 64-deep image of gemm_pers_kernel's K64 form: 128-byte rows, fragments 2 KiB apart
+#define MOCR_W2K_READ_HEAD(F, aA, aB)                                                                                   \
+    asm volatile("ds_read_b128 %0, %7\n\tds_read_b128 %1, %7 offset:2048\n\tds_read_b128 %2, %7 offset:4096\n\t"        \
+                 "ds_read_b128 %3, %7 offset:6144\n\tds_read_b128 %4, %6\n\tds_read_b128 %5, %6 offset:2048"             \
+                 : "=&v"(F.fb[0]), "=&v"(F.fb[1]), "=&v"(F.fb[2]), "=&v"(F.fb[3]), "=&v"(F.fa[0]), "=&v"(F.fa[1])       \
+                 : "v"(aA), "v"(aB)                                                                                      \
+                 : "memory")
+#define MOCR_W2K_READ_TAIL(F, aA)                                                                                       \
+    asm volatile("ds_read_b128 %0, %6 offset:4096\n\tds_read_b128 %1, %6 offset:6144\n\tds_read_b128 %2, %6 offset:8192\n\t" \
+                 "ds_read_b128 %3, %6 offset:10240\n\tds_read_b128 %4, %6 offset:12288\n\tds_read_b128 %5, %6 offset:14336" \
+                 : "=&v"(F.fa[2]), "=&v"(F.fa[3]), "=&v"(F.fa[4]), "=&v"(F.fa[5]), "=&v"(F.fa[6]), "=&v"(F.fa[7])       \
+                 : "v"(aA)                                                                                               \
+                 : "memory")
 // a half tile's wave (64 x 64, gemm_pers_kernel STRIP): A fragments 2 and 3 only
 #define MOCR_W2_READ_TAIL2(F, aA)                                                                                       \
     asm volatile("ds_read_b128 %0, %2 offset:2048\n\tds_read_b128 %1, %2 offset:3072"                                   \

@@ -40,6 +40,15 @@ template <int CTRL> __device__ __forceinline__ float dpp_f32(float v) {
     return __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), CTRL, 0xf, 0xf, false));
 }
 
+// K64 (r03, second session): with the one-barrier-per-two-K-tiles schedule (PAIR) the LDS image of a pair of K-tiles is
+// ONE 64-deep tile of 128-byte rows: a DMA request then covers 8 rows x 128 B - eight whole cache lines - instead of 16
+// rows x 64 B - sixteen half lines.  tools/probe/dma_probe.hip: the LDS-DMA stream of this kernel's operand pattern (A
+// panels shared by 8-32 blocks of an XCD, one W slice for all) runs at 55-61 GB/s per CU in 64-byte rows and at 94-117
+// GB/s per CU in 128-byte rows; the K loops ran at the former rate.  -DMOCR_PERS_K64=0 builds the 32-deep image for A/B.
+#ifndef MOCR_PERS_K64
+#define MOCR_PERS_K64 1
+#endif
+
 constexpr int PERS_LDS = 160 * 1024;      // four 32 KiB ring slots + 32 KiB that only the epilogue uses
 
 // SPLIT_DMA: the LDS-DMA of a K-tile is requested by waves 0-3 alone (8 pieces each; those waves then never have a
@@ -64,6 +73,11 @@ template <int EPI, bool SPLIT_DMA, bool PAIR = false, bool STRIP = false, bool L
 __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
     static_assert(!STRIP || SPLIT_DMA, "the strip schedule is built on the split-role kernel");
     constexpr int BM = 256, BN = 256, WN = 4;
+    constexpr bool K64 = PAIR && (MOCR_PERS_K64 != 0);
+    static_assert(!K64 || SPLIT_DMA, "the 64-deep image is requested by waves 0-3, eight pieces of one operand per batch");
+    // 32-deep image: slot = [A 256 x 64 B][W 256 x 64 B] per K-tile, four slots.  K64: two 64-KiB slots per PAIR of K-tiles,
+    // [A 256 x 128 B][W 256 x 128 B]; a "K-tile" g is then k-step g & 1 of 64-deep tile g >> 1, and the request batch g is
+    // the A rows (g even) or the W rows (g odd) of that tile.
     constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64, STAGE = A_BYTES + B_BYTES;   // 32 KiB per 32-deep K-tile
     constexpr int RING = 4 * STAGE;                                                  // 128 KiB; + 32 KiB spare = 160 KiB
     static_assert(EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID, "epilogues of the encoder layers");
@@ -161,8 +175,11 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
     // K-tile (r03 measurement: with the eight requests of a K-tile on four waves those waves' issue time - ~35 visible
     // cycles per request - was the K loop's critical path: +18..30 % over the loop without DMA).
     // Lane -> row lane>>2 of the piece, logical chunk (lane&3) ^ 2*((row>>3)&1).
-    const int drow = lane >> 2, dchunk = (lane & 3) ^ (((lane >> 5) & 1) << 1);
-    const size_t a_lane = (size_t)(wave * 16 + drow) * a_row + dchunk * 16, w_lane = (size_t)(wave * 16 + drow) * w_row + dchunk * 16;
+    // K64: piece = 8 rows x 128 B; wave w requests pieces w, w + 4, ... (eight of one operand per batch); lane -> row lane>>3 of
+    // the piece, logical 16-byte chunk (lane & 7) ^ ((row >> 1) & 7) - the same for all of a wave's pieces (8 (w + 4 i) rows)
+    const int drow = K64 ? lane >> 3 : lane >> 2;
+    const int dchunk = K64 ? (lane & 7) ^ ((4 * wave + (lane >> 4)) & 7) : (lane & 3) ^ (((lane >> 5) & 1) << 1);
+    const size_t a_lane = (size_t)(wave * (K64 ? 8 : 16) + drow) * a_row + dchunk * 16, w_lane = (size_t)(wave * (K64 ? 8 : 16) + drow) * w_row + dchunk * 16;
     constexpr int NPIECE = SPLIT_DMA ? 4 : 2, PSTEP = SPLIT_DMA ? 4 : 8, LPT = 2 * NPIECE;      // per wave and K-tile: A pieces, W pieces; requests
     const bool issues_dma = !SPLIT_DMA || dma_wave;
     int pf_tile = tile, pf_kt = 0;               // the next K-tile to request: (pf_tile, pf_kt), global index pf_g
@@ -184,6 +201,25 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
         if (pf_tile >= tile_end) return;
         if (!issues_dma) { ++pf_g; if (++pf_kt == nt) { pf_kt = 0; pf_tile += tstride; } return; }
         if ((ablate & 2) && pf_g >= 3) { ++pf_g; if (++pf_kt == nt) { pf_kt = 0; pf_tile += tstride; } return; }      // diagnostics: K loop without DMA
+        if constexpr (K64) {
+            // batch pf_g: eight pieces of A (even) or of W (odd) of 64-deep tile pf_g >> 1, into its slot's A / W half
+            char* const dst = smem + ((pf_g >> 1) & 1) * (2 * STAGE) + (pf_g & 1) * (2 * A_BYTES) + wave * 1024;
+            const bool w_batch = pf_g & 1;
+            const char* const src = (w_batch ? pf_w : pf_a) + (size_t)(pf_kt >> 1) * 128;
+            const size_t rstep = (size_t)32 * (w_batch ? w_row : a_row);      // pieces w + 4 i: 32 rows apart
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (STRIP && pf_half && !w_batch && i >= 4) continue;       // a half tile has no A rows 128..255
+                glds16(src + rstep * i, dst + i * 4096);
+            }
+            ++pf_g;
+            if (++pf_kt == nt) {
+                pf_kt = 0;
+                pf_tile += tstride;
+                if (pf_tile < tile_end) pf_set();
+            }
+            return;
+        }
         char* sa = smem + (pf_g & 3) * STAGE + wave * 1024;
         const char* ga = pf_a + (size_t)pf_kt * 64;
         const char* gw = pf_w + (size_t)pf_kt * 64;
@@ -205,8 +241,11 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
         }
     };
 
-    const int frag_off = l15 * 64 + ((g4 ^ (((l15 >> 3) & 1) << 1)) << 4);
-    const unsigned offA = lds_addr_of(smem) + (wm * 128) * 64 + frag_off, offB = lds_addr_of(smem) + A_BYTES + (wn * 64) * 64 + frag_off;
+    // K64: row r of the 64-deep image at r * 128, logical chunk c (k-step s: c = 4 s + g4) at chunk c ^ ((r >> 1) & 7): the
+    // address of k-step 1 is the address of k-step 0 with bit 6 flipped; fragments 16 rows = 2 KiB apart
+    const int frag_off = K64 ? l15 * 128 + ((g4 ^ ((l15 >> 1) & 7)) << 4) : l15 * 64 + ((g4 ^ (((l15 >> 3) & 1) << 1)) << 4);
+    const unsigned offA = lds_addr_of(smem) + (wm * 128) * (K64 ? 128 : 64) + frag_off;
+    const unsigned offB = lds_addr_of(smem) + (K64 ? 2 * A_BYTES : A_BYTES) + (wn * 64) * (K64 ? 128 : 64) + frag_off;
 
     // EPI_BIAS_RESID: the accumulators START as the tile's residual rows (out = resid + A.W^T + bias): the residual is
     // read in the accumulator layout - lane: 16 bytes of row 16i + l15, columns 16j + 4 g4 - for tile i + 1 while tile i's
@@ -246,13 +285,14 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
     asm volatile("" ::: "memory");
     // STRIP: a half tile's wave reads its A fragments from rows 64 wm .. of the K-tile instead of 128 wm ..: `hadj` bytes
     // lower (hadj: the tile being multiplied; hadj_nx: the block's next tile)
-    const unsigned hadj_unit = STRIP ? (unsigned)(wm * 64 * 64) : 0u;
+    const unsigned hadj_unit = STRIP ? (unsigned)(wm * 64 * (K64 ? 128 : 64)) : 0u;
     unsigned hadj = 0, hadj_nx = 0;
     if constexpr (STRIP) {
         if (tile == s_hpos) hadj = hadj_unit;
     }
     WideFrags P, Q;
-    MOCR_W2_READ_HEAD(P, offA - hadj, offB);
+    if constexpr (K64) { MOCR_W2K_READ_HEAD(P, offA - hadj, offB); }
+    else { MOCR_W2_READ_HEAD(P, offA - hadj, offB); }
 
     // one K-tile: CUR holds its first six fragments (requested during the previous K-tile), NXT receives those of the next
 #define MOCR_PERS_KTILE(CUR, NXT)                                                                                      \
@@ -329,6 +369,47 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
         ++g;                                                                                                           \
     }
 
+    // K64 forms of the two: k-step 0 (g even) and k-step 1 (g odd) of the 64-deep tile g >> 1 in slot (g >> 1) & 1
+#define MOCR_PERS_KTILE_A64(CUR, NXT)                                                                                  \
+    {                                                                                                                  \
+        const unsigned st = (unsigned)(((g >> 1) & 1) * (2 * STAGE));                                                   \
+        MOCR_W2K_READ_TAIL(CUR, offA + st - hadj);                                                                     \
+        stage_next();                                     /* batch g + 3: the W rows of tile (g >> 1) + 1 */            \
+        asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(CUR.fb[0]), "+v"(CUR.fb[1]), "+v"(CUR.fb[2]), "+v"(CUR.fb[3]),      \
+                     "+v"(CUR.fa[0]), "+v"(CUR.fa[1]));                                                                \
+        MOCR_W2_GROUP(CUR, 0);                                                                                         \
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(CUR.fa[2]), "+v"(CUR.fa[3]));                                       \
+        MOCR_W2_GROUP(CUR, 1);                                                                                         \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(CUR.fa[4]), "+v"(CUR.fa[5]), "+v"(CUR.fa[6]), "+v"(CUR.fa[7]));     \
+        MOCR_W2K_READ_HEAD(NXT, (offA + st - hadj) ^ 64u, (offB + st) ^ 64u);      /* k-step 1 of the same tile */       \
+        if (!(STRIP && half)) {                                                                                        \
+            MOCR_W2_GROUP(CUR, 2);                                                                                     \
+            MOCR_W2_GROUP(CUR, 3);                                                                                     \
+        }                                                                                                              \
+        ++g;                                                                                                           \
+    }
+#define MOCR_PERS_KTILE_B64(CUR, NXT)                                                                                  \
+    {                                                                                                                  \
+        const unsigned st = (unsigned)(((g >> 1) & 1) * (2 * STAGE)), sn = (unsigned)((((g + 1) >> 1) & 1) * (2 * STAGE)); \
+        MOCR_W2K_READ_TAIL(CUR, (offA + st - hadj) ^ 64u);                                                             \
+        asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(CUR.fb[0]), "+v"(CUR.fb[1]), "+v"(CUR.fb[2]), "+v"(CUR.fb[3]),      \
+                     "+v"(CUR.fa[0]), "+v"(CUR.fa[1]));                                                                \
+        MOCR_W2_GROUP(CUR, 0);                                                                                         \
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(CUR.fa[2]), "+v"(CUR.fa[3]));                                       \
+        MOCR_W2_GROUP(CUR, 1);                                                                                         \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(CUR.fa[4]), "+v"(CUR.fa[5]), "+v"(CUR.fa[6]), "+v"(CUR.fa[7]));     \
+        if (issues_dma) wait_vmcnt<0>();                  /* tile (g >> 1) + 1 has landed (own pieces) */               \
+        __builtin_amdgcn_s_barrier();                     /* ... everyone's; this tile's slot is free */                \
+        asm volatile("" ::: "memory");                                                                                 \
+        stage_next();                                     /* batch g + 3: the A rows of tile (g >> 1) + 2, into this tile's slot */ \
+        MOCR_W2K_READ_HEAD(NXT, offA + sn - hadj_h, offB + sn);                                                        \
+        if (!(STRIP && half)) {                                                                                        \
+            MOCR_W2_GROUP(CUR, 2);                                                                                     \
+            MOCR_W2_GROUP(CUR, 3);                                                                                     \
+        }                                                                                                              \
+        ++g;                                                                                                           \
+    }
+
     for (; tile < tile_end; tile += tstride) {
         int m0, n0, row_lo, row_hi;
         bool half;
@@ -388,7 +469,10 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
             for (int t = 0; t < nt; t += 2) {
                 if (t + 2 >= nt) ln_handover();
                 const unsigned hadj_h = t + 2 < nt ? hadj : hadj_nx;      // the tile of the K-tile behind this pair
-                if constexpr (PAIR) {
+                if constexpr (K64) {
+                    MOCR_PERS_KTILE_A64(P, Q)
+                    MOCR_PERS_KTILE_B64(Q, P)
+                } else if constexpr (PAIR) {
                     MOCR_PERS_KTILE_A(P, Q)
                     MOCR_PERS_KTILE_B(Q, P)
                 } else {
@@ -399,8 +483,14 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
         } else if constexpr (PAIR) {
             constexpr unsigned hadj_h = 0;
             for (int t = 0; t < nt; t += 2) {
-                MOCR_PERS_KTILE_A(P, Q)
-                MOCR_PERS_KTILE_B(Q, P)
+                if (t + 2 >= nt) ln_handover();
+                if constexpr (K64) {
+                    MOCR_PERS_KTILE_A64(P, Q)
+                    MOCR_PERS_KTILE_B64(Q, P)
+                } else {
+                    MOCR_PERS_KTILE_A(P, Q)
+                    MOCR_PERS_KTILE_B(Q, P)
+                }
             }
         } else {
             constexpr unsigned hadj_k = 0;
@@ -427,8 +517,8 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) { asm volatile("" :: "v"(acc[j][i])); acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
             if constexpr (LNF || STRIP) {
-                const unsigned sg = (unsigned)((g & 3) * STAGE);
-                MOCR_W2_READ_HEAD(P, offA + sg - hadj_nx, offB + sg);
+                if constexpr (K64) { const unsigned sg = (unsigned)(((g >> 1) & 1) * (2 * STAGE)); MOCR_W2K_READ_HEAD(P, offA + sg - hadj_nx, offB + sg); }
+                else { const unsigned sg = (unsigned)((g & 3) * STAGE); MOCR_W2_READ_HEAD(P, offA + sg - hadj_nx, offB + sg); }
             }
             continue;
         }
@@ -437,7 +527,8 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
         int ldo = p.ldo;
         asm volatile("" : "+s"(ldo));
         char* const piece0 = smem + RING;
-        char* const piece1 = smem + ((g - 1) & 3) * STAGE;
+        // (K64: the W half of the last 64-deep tile's slot - its A half already receives the tile after next)
+        char* const piece1 = K64 ? smem + (((g - 1) >> 1) & 1) * (2 * STAGE) + 2 * A_BYTES : smem + ((g - 1) & 3) * STAGE;
         if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
             [[maybe_unused]] float cs[4][4], mu[8], rs[8];
             if constexpr (LNF) {
@@ -632,13 +723,15 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
             }
         }
         if (give_up_p) {
-            const unsigned sg = (unsigned)((g & 3) * STAGE);
-            MOCR_W2_READ_HEAD(P, offA + sg - hadj_nx, offB + sg);
+            if constexpr (K64) { const unsigned sg = (unsigned)(((g >> 1) & 1) * (2 * STAGE)); MOCR_W2K_READ_HEAD(P, offA + sg - hadj_nx, offB + sg); }
+            else { const unsigned sg = (unsigned)((g & 3) * STAGE); MOCR_W2_READ_HEAD(P, offA + sg - hadj_nx, offB + sg); }
         }
     }
 #undef MOCR_PERS_KTILE
 #undef MOCR_PERS_KTILE_A
 #undef MOCR_PERS_KTILE_B
+#undef MOCR_PERS_KTILE_A64
+#undef MOCR_PERS_KTILE_B64
     // the reads requested behind the last barrier: landed before their registers are used for anything else
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(P.fb[0]), "+v"(P.fb[1]), "+v"(P.fb[2]), "+v"(P.fb[3]), "+v"(P.fa[0]), "+v"(P.fa[1]));
 }

@@ -18,7 +18,7 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 
 // DEEP: 32 (64-byte rows, 16 rows per request) or 64 (128-byte rows, 8 rows per request); WAVES: waves that request (4 or 8)
 template <int DEEP, int WAVES>
-__global__ __launch_bounds__(512, 1) void dma_k(const char* A, const char* W, int panels, int row_bytes, unsigned long long* rt) {
+__global__ __launch_bounds__(512, 1) void dma_k(const char* A, const char* W, int panels, int row_bytes, int share, unsigned long long* rt) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ROWB = DEEP * 2;                    // bytes of a tile row
     constexpr int RPR = 1024 / ROWB;                  // rows per request
@@ -32,7 +32,10 @@ __global__ __launch_bounds__(512, 1) void dma_k(const char* A, const char* W, in
     const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
     int g = 0;
     for (int pnl = 0; pnl < panels; ++pnl) {
-        const char* a = A + ((size_t)(pnl * gridDim.x + blockIdx.x) * 256) * row_bytes;
+        // `share` blocks that are neighbours in one XCD's block order (b, b + 8, ...) read the same panel, as the column
+        // blocks of one A row-panel do in the GEMM (share = 1: every block streams its own panel from HBM)
+        const int grp = (int)(blockIdx.x & 7) + 8 * (int)((blockIdx.x >> 3) / share);
+        const char* a = A + ((size_t)(pnl * gridDim.x + grp) * 256) * row_bytes;
         for (int kt = 0; kt < nk; ++kt, ++g) {
             if (wave < WAVES) {
                 char* slot = smem + (g % SLOTS) * TILE;
@@ -64,13 +67,13 @@ __global__ __launch_bounds__(512, 1) void dma_k(const char* A, const char* W, in
 }
 
 template <int DEEP, int WAVES>
-static void run(const char* A, const char* W, int blocks, int panels, int row_bytes, unsigned long long* dr, const char* what) {
+static void run(const char* A, const char* W, int blocks, int panels, int row_bytes, int share, unsigned long long* dr, const char* what) {
     CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(dma_k<DEEP, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     for (int rep = 0; rep < 2; ++rep) {
         CHECK(hipEventRecord(e0));
-        hipLaunchKernelGGL((dma_k<DEEP, WAVES>), dim3(blocks), dim3(512), 160 * 1024, 0, A, W, panels, row_bytes, dr);
+        hipLaunchKernelGGL((dma_k<DEEP, WAVES>), dim3(blocks), dim3(512), 160 * 1024, 0, A, W, panels, row_bytes, share, dr);
         CHECK(hipEventRecord(e1));
         CHECK(hipDeviceSynchronize());
     }
@@ -81,7 +84,7 @@ static void run(const char* A, const char* W, int blocks, int panels, int row_by
     std::sort(r.begin(), r.end());
     const double bytes_per_block = (double)panels * 512.0 * row_bytes;
     const double us_med = r[blocks / 2] / 100.0;       // s_memrealtime: 100 MHz
-    printf("%-44s: launch %8.1f us  -> %6.2f TB/s chip, %6.1f GB/s per CU (median block %8.1f us)\n", what, ms * 1e3,
+    printf("share %2d  %-44s: launch %8.1f us  -> %6.2f TB/s chip, %6.1f GB/s per CU (median block %8.1f us)\n", share, what, ms * 1e3,
            bytes_per_block * blocks / (ms * 1e-3) / 1e12, bytes_per_block / (us_med * 1e-6) / 1e9, us_med);
 }
 
@@ -99,11 +102,11 @@ int main() {
     CHECK(hipMemset(A, 1, abytes));
     CHECK(hipMemset(W, 2, (size_t)256 * row_bytes));
     printf("%d CUs, %d panels of 256 rows x %d B per block (%.0f MB of A in all) + a shared 256-row W slice\n", blocks, panels, row_bytes, abytes / 1e6);
-    for (int rep = 0; rep < 2; ++rep) {
-        run<32, 4>(A, W, blocks, panels, row_bytes, dr, "32-deep K-tiles (16 rows x 64 B), 4 waves");
-        run<32, 8>(A, W, blocks, panels, row_bytes, dr, "32-deep K-tiles (16 rows x 64 B), 8 waves");
-        run<64, 4>(A, W, blocks, panels, row_bytes, dr, "64-deep K-tiles (8 rows x 128 B), 4 waves");
-        run<64, 8>(A, W, blocks, panels, row_bytes, dr, "64-deep K-tiles (8 rows x 128 B), 8 waves");
+    for (int share : {1, 8, 32}) {
+        run<32, 4>(A, W, blocks, panels, row_bytes, share, dr, "32-deep K-tiles (16 rows x 64 B), 4 waves");
+        run<32, 8>(A, W, blocks, panels, row_bytes, share, dr, "32-deep K-tiles (16 rows x 64 B), 8 waves");
+        run<64, 4>(A, W, blocks, panels, row_bytes, share, dr, "64-deep K-tiles (8 rows x 128 B), 4 waves");
+        run<64, 8>(A, W, blocks, panels, row_bytes, share, dr, "64-deep K-tiles (8 rows x 128 B), 8 waves");
     }
     return 0;
 }

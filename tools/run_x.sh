@@ -1,3 +1,15 @@
 #!/bin/bash
-export MOCR_LIB=manga-ocr_amd/manga_ocr/_lib/libmocr_hip_lab.so
-for ab in 0 4096 0 4096; do echo "ablate $ab"; MOCR_GEMM_ABLATE=$ab timeout -k 10 200 python tools/ln_fold_bench.py 2>&1 | grep -E "qkv|fc1"; done
+set -o pipefail
+O=gpurun_out/r3t
+mkdir -p $O
+run() { name=$1; shift; env "$@" timeout -k 10 300 python bench.py --no-cpu-baseline --no-config4 --no-parity-leg --steps 10 > $O/$name.json 2> $O/$name.err; python - <<PY
+import json
+d=json.load(open("$O/$name.json"))
+e=d.get("encoder_only") or {}
+print("$name", "value", round(d["value"]), "enc", round(e.get("kernel_ms",0),2), round(e.get("frac_of_mfma_peak",0),4), [(k[0][5:],k[2]) for k in e.get("kernels")][:6])
+PY
+}
+run k64 MOCR_X=0
+run old MOCR_LIB=manga-ocr_amd/manga_ocr/_lib/libmocr_hip_lab32.so MOCR_GEMM_PAIR_BF16=0
+run k64b MOCR_X=0
+run old2 MOCR_LIB=manga-ocr_amd/manga_ocr/_lib/libmocr_hip_lab32.so MOCR_GEMM_PAIR_BF16=0
