@@ -527,6 +527,14 @@ void gemm(mocr_engine* e, const char* name, const void* A, int lda, const void* 
     }
     static const int ablate = env_int("MOCR_GEMM_ABLATE", 0);
     p.ablate = ablate;
+#ifdef MOCR_EXPERIMENTS
+    static unsigned long long* stamp_buf = nullptr;      // diagnostics: MOCR_GEMM_ABLATE & 8192 (kernels_gemm_pers.h, MOCR_STAMP)
+    if ((ablate & 8192) && tile >= 4096 && epi != EPI_PATCH) {
+        if (!stamp_buf) HIPCHECK(hipMalloc(&stamp_buf, 1024 * 8 * 4 * 8));
+        HIPCHECK(hipMemsetAsync(stamp_buf, 0, 1024 * 8 * 4 * 8, e->stream));
+        p.pos = reinterpret_cast<const float*>(stamp_buf);
+    }
+#endif
     static const int group_env = env_int("MOCR_GEMM_GROUPN", -1);
     p.group_n = group_env >= 0 ? group_env : group_n;
     const double out_b = (epi == EPI_BIAS || epi == EPI_BIAS_GELU) ? sizeof(T) : 4.0;
@@ -551,6 +559,8 @@ void gemm(mocr_engine* e, const char* name, const void* A, int lda, const void* 
     else if (tile == 4098) launch_gemm_pers<false>(e, p, epi, 0);   // experiment: every wave requests LDS-DMA
     else if (tile == 4101) launch_gemm_pers<true, true>(e, p, epi, 0);    // experiment: one barrier per two K-tiles
     else if (tile == 4102) launch_gemm_pers<true, true>(e, p, epi, 8);
+    else if (tile == 4105) launch_gemm_pers<false, true>(e, p, epi, 0);        // experiment: the pair loop with every wave requesting LDS-DMA
+    else if (tile == 4106) launch_gemm_pers<false, true>(e, p, epi, 8);
     else if (tile == 4103) launch_gemm_pers<true, false>(e, p, epi, 0, 1);      // experiment: strips on the one-barrier-per-K-tile loop
     else if (tile == 4104) launch_gemm_pers<true, false>(e, p, epi, 8, 1);
     else if (tile == 2048) launch_gemm_wide2(e, p, epi);
@@ -564,6 +574,26 @@ void gemm(mocr_engine* e, const char* name, const void* A, int lda, const void* 
     else if (tile == 128) launch_gemm_epi<T, 128, 128>(e, p, epi, split, ybatch);
     else if (tile == 64) launch_gemm_epi<T, 64, 64>(e, p, epi, split, ybatch);
     else throw ArgError{"gemm tile must be 64, 128 or 4096", MOCR_ERR_ARG};
+#ifdef MOCR_EXPERIMENTS
+    if ((ablate & 8192) && tile >= 4096 && stamp_buf) {
+        HIPCHECK(hipStreamSynchronize(e->stream));
+        std::vector<unsigned long long> h(256 * 8 * 4);
+        HIPCHECK(hipMemcpy(h.data(), stamp_buf, h.size() * 8, hipMemcpyDeviceToHost));
+        double s0[2] = {0, 0}, s1[2] = {0, 0}, s2[2] = {0, 0}, pairs = 0;
+        int nb = 0;
+        for (int b = 0; b < 256; ++b) {
+            if (!h[(b * 8) * 4 + 3]) continue;
+            ++nb;
+            pairs += (double)h[(b * 8) * 4 + 3] / 2;
+            for (int w = 0; w < 8; ++w) { s0[w >> 2] += h[(b * 8 + w) * 4]; s1[w >> 2] += h[(b * 8 + w) * 4 + 1]; s2[w >> 2] += h[(b * 8 + w) * 4 + 2]; }
+        }
+        if (nb) {
+            const double n = pairs * 4;      // wave-pairs per role
+            fprintf(stderr, "[stamps] %s: %d blocks, %.0f K-tile pairs each; cycles per pair  DMA waves: work %.0f, DMA wait %.0f, barrier %.0f | store waves: work %.0f, -, barrier %.0f\n",
+                    name, nb, pairs / nb, s0[0] / n, s1[0] / n, s2[0] / n, s0[1] / n, (s1[1] + s2[1]) / n);
+        }
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------- encoder
@@ -1186,6 +1216,9 @@ template <typename T> void init_kernel_attrs() {
     set_max_lds(gemm_pers_kernel<EPI_BIAS, true, true, false, true>, PERS_LDS);
     set_max_lds(gemm_pers_kernel<EPI_BIAS_GELU, true, true, false, true>, PERS_LDS);
 #ifdef MOCR_EXPERIMENTS
+    set_max_lds(gemm_pers_kernel<EPI_BIAS, false, true>, PERS_LDS);
+    set_max_lds(gemm_pers_kernel<EPI_BIAS_GELU, false, true>, PERS_LDS);
+    set_max_lds(gemm_pers_kernel<EPI_BIAS_RESID, false, true>, PERS_LDS);
     set_max_lds(gemm_pers_kernel<EPI_BIAS, false>, PERS_LDS);
     set_max_lds(gemm_pers_kernel<EPI_BIAS_GELU, false>, PERS_LDS);
     set_max_lds(gemm_pers_kernel<EPI_BIAS_RESID, false>, PERS_LDS);

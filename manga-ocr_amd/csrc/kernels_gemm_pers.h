@@ -74,7 +74,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
     static_assert(!STRIP || SPLIT_DMA, "the strip schedule is built on the split-role kernel");
     constexpr int BM = 256, BN = 256, WN = 4;
     constexpr bool K64 = PAIR && (MOCR_PERS_K64 != 0);
-    static_assert(!K64 || SPLIT_DMA, "the 64-deep image is requested by waves 0-3, eight pieces of one operand per batch");
+    constexpr int DW = SPLIT_DMA ? 4 : 8;             // waves that request LDS-DMA
     // 32-deep image: slot = [A 256 x 64 B][W 256 x 64 B] per K-tile, four slots.  K64: two 64-KiB slots per PAIR of K-tiles,
     // [A 256 x 128 B][W 256 x 128 B]; a "K-tile" g is then k-step g & 1 of 64-deep tile g >> 1, and the request batch g is
     // the A rows (g even) or the W rows (g odd) of that tile.
@@ -206,11 +206,11 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
             char* const dst = smem + ((pf_g >> 1) & 1) * (2 * STAGE) + (pf_g & 1) * (2 * A_BYTES) + wave * 1024;
             const bool w_batch = pf_g & 1;
             const char* const src = (w_batch ? pf_w : pf_a) + (size_t)(pf_kt >> 1) * 128;
-            const size_t rstep = (size_t)32 * (w_batch ? w_row : a_row);      // pieces w + 4 i: 32 rows apart
+            const size_t rstep = (size_t)(8 * DW) * (w_batch ? w_row : a_row);      // pieces w + DW i: 8 DW rows apart
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                if (STRIP && pf_half && !w_batch && i >= 4) continue;       // a half tile has no A rows 128..255
-                glds16(src + rstep * i, dst + i * 4096);
+            for (int i = 0; i < 32 / DW; ++i) {
+                if (STRIP && pf_half && !w_batch && i >= 16 / DW) continue;       // a half tile has no A rows 128..255
+                glds16(src + rstep * i, dst + i * (DW * 1024));
             }
             ++pf_g;
             if (++pf_kt == nt) {
@@ -369,6 +369,24 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
         ++g;                                                                                                           \
     }
 
+    // diagnostics (experiments build, MOCR_GEMM_ABLATE & 8192): cycles per wave between the pair barriers - [0] multiply +
+    // request (barrier exit .. ready for the DMA wait), [1] the DMA wait, [2] the barrier - summed over the block's K loops
+    // and written to p.pos [block][wave][4] (s_memtime is a scalar-memory read: stamped only where lgkmcnt is 0 anyway)
+#ifdef MOCR_EXPERIMENTS
+    unsigned long long stamp_prev = 0, stamp_acc0 = 0, stamp_acc1 = 0, stamp_acc2 = 0;
+    const bool stamping = (ablate & 8192) != 0;
+#define MOCR_STAMP(k)                                                                                                  \
+    if (stamping) {                                                                                                    \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                                  \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                             \
+        if ((k) == 0) { if (stamp_prev) stamp_acc0 += now_ - stamp_prev; }                                             \
+        else if ((k) == 1) stamp_acc1 += now_ - stamp_prev;                                                            \
+        else stamp_acc2 += now_ - stamp_prev;                                                                          \
+        stamp_prev = now_;                                                                                             \
+    }
+#else
+#define MOCR_STAMP(k)
+#endif
     // K64 forms of the two: k-step 0 (g even) and k-step 1 (g odd) of the 64-deep tile g >> 1 in slot (g >> 1) & 1
 #define MOCR_PERS_KTILE_A64(CUR, NXT)                                                                                  \
     {                                                                                                                  \
@@ -398,9 +416,12 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
         asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(CUR.fa[2]), "+v"(CUR.fa[3]));                                       \
         MOCR_W2_GROUP(CUR, 1);                                                                                         \
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(CUR.fa[4]), "+v"(CUR.fa[5]), "+v"(CUR.fa[6]), "+v"(CUR.fa[7]));     \
+        MOCR_STAMP(0);                                                                                                 \
         if (issues_dma) wait_vmcnt<0>();                  /* tile (g >> 1) + 1 has landed (own pieces) */               \
+        MOCR_STAMP(1);                                                                                                 \
         __builtin_amdgcn_s_barrier();                     /* ... everyone's; this tile's slot is free */                \
         asm volatile("" ::: "memory");                                                                                 \
+        MOCR_STAMP(2);                                                                                                 \
         stage_next();                                     /* batch g + 3: the A rows of tile (g >> 1) + 2, into this tile's slot */ \
         MOCR_W2K_READ_HEAD(NXT, offA + sn - hadj_h, offB + sn);                                                        \
         if (!(STRIP && half)) {                                                                                        \
@@ -681,6 +702,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
                             const bool mine = STRIP ? (unsigned)row - own_lo < own_n : (!guard || m0 + row < p.M);
                             const float4 o = make_float4(v[it].x + bias_row.x, v[it].y + bias_row.y, v[it].z + bias_row.z, v[it].w + bias_row.w);
                             if (mine && !(ablate & 8)) {
+                                // (non-temporal here measured r03: no difference - 12.74-12.81 against 12.82-13.01 ms for the encoder)
                                 *reinterpret_cast<float4*>(obase + (size_t)row * ldo) = o;
                                 if (LNF && !(ablate & 64)) {
                                     uint2 u;
@@ -732,6 +754,13 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
 #undef MOCR_PERS_KTILE_B
 #undef MOCR_PERS_KTILE_A64
 #undef MOCR_PERS_KTILE_B64
+#ifdef MOCR_EXPERIMENTS
+    if (stamping && lane == 0 && p.pos) {
+        unsigned long long* d = reinterpret_cast<unsigned long long*>(const_cast<float*>(p.pos)) + ((size_t)blockIdx.x * 8 + wave) * 4;
+        d[0] = stamp_acc0; d[1] = stamp_acc1; d[2] = stamp_acc2; d[3] = (unsigned long long)g;
+    }
+#endif
+#undef MOCR_STAMP
     // the reads requested behind the last barrier: landed before their registers are used for anything else
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(P.fb[0]), "+v"(P.fb[1]), "+v"(P.fb[2]), "+v"(P.fb[3]), "+v"(P.fa[0]), "+v"(P.fa[1]));
 }

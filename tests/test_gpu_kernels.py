@@ -106,7 +106,8 @@ def test_gemm_256x128_three_stage_ring(M, N, K, epi, tile):
 
 @pytest.mark.parametrize("epi", [EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID])
 @pytest.mark.parametrize("tile,M,N,K", [(4096, 8900, 2304, 768), (4097, 2500, 768, 3072), (4097, 1300, 3072, 128), (4096, 33000, 768, 768)] +
-                         ([(4098, 8900, 2304, 768), (4101, 8900, 2304, 768), (4102, 2500, 768, 3072), (4102, 1300, 3072, 128)] if LAB else []))
+                         ([(4098, 8900, 2304, 768), (4101, 8900, 2304, 768), (4102, 2500, 768, 3072), (4102, 1300, 3072, 128),
+                           (4105, 8900, 2304, 768), (4106, 2500, 768, 3072), (4106, 1300, 3072, 128)] if LAB else []))
 def test_gemm_persistent_blocks_walk_several_tiles(epi, tile, M, N, K):
     """gemm_pers_kernel (tile code 4096; 4097 = the same kernel on 8 blocks): a block multiplies a SEQUENCE of 256 x 256
     tiles - the LDS ring runs across tile boundaries, the epilogue is staged through the slot the last K-tile left, and

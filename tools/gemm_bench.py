@@ -36,7 +36,7 @@ def enc_shapes(M):
     out = []
     for name, N, K, epi in (("enc_qkv", 2304, 768, "bias"), ("enc_oproj", 768, 768, "resid"), ("enc_fc1", 3072, 768, "gelu"),
                             ("enc_fc2", 768, 3072, "resid")):
-        for tile in (128, 256, 512, 1024, 2048, 4096, 4098, 4099, 4101, 4103):
+        for tile in (128, 256, 512, 1024, 2048, 4096, 4098, 4099, 4101, 4103, 4105):
             out.append((f"{name} t{tile}", M, N, K, epi, tile, 1))
     return out
 
