@@ -150,6 +150,11 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
         const int units = (int)((blockIdx.x >> 3) & 3) * stagger / 4;
         for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(16);
     }
+#ifdef MOCR_EXPERIMENTS
+    // diagnostics (MOCR_GEMM_ABLATE & 32768 / 65536): static priority for the requesting waves / for the store waves
+    if ((ablate & 32768) && dma_wave) __builtin_amdgcn_s_setprio(1);
+    if ((ablate & 65536) && !dma_wave) __builtin_amdgcn_s_setprio(1);
+#endif
     const int nt = p.k_per_split / 32;            // even, >= 4 (checked on the host)
     const size_t a_row = (size_t)p.lda * 2, w_row = (size_t)p.ldw * 2;
     const bool guard = STRIP || (p.M & (BM - 1)) != 0;
