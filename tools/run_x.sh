@@ -1,3 +1,7 @@
 #!/bin/bash
-export MOCR_LIB=manga-ocr_amd/manga_ocr/_lib/libmocr_hip_lab.so
-for ab in 0 32768 65536 0 32768; do echo "ablate $ab"; MOCR_GEMM_ABLATE=$ab timeout -k 10 300 python tools/gemm_bench.py enc 50432 t4096 2>&1 | grep -E "t4096"; done
+# final r03 numbers: the bench lines kept under profiles/ and the three rocprofv3 passes
+set -o pipefail
+rm -rf gpurun_out/prof_r03b
+bash tools/run_final.sh
+bash tools/profile_passes.sh gpurun_out/prof_r03b > gpurun_out/prof_r03b.log 2>&1; echo "profile rc=$?"
+tail -3 gpurun_out/prof_r03b.log
