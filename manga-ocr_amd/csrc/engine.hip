@@ -404,8 +404,10 @@ static bool pers_strip_wins(int M, int ntn, int grid) {
     const int R = pers_strip_rows(M, ntn, grid);
     if (!R) return false;
     const int rem = R & 255;
+    // (a half tile: 0.5-0.75 of a tile by its K; FC1 at batch 256 - 9 tiles + a half tile against 10 - measured 274-279 ->
+    // 265-271 us with the 64-deep image)
     const double strip_cost = (R >> 8) + (rem == 0 ? 0.0 : rem <= 128 ? 0.6 : 1.0);
-    return strip_cost <= 0.95 * per_block;
+    return strip_cost <= 0.965 * per_block;
 }
 
 template <int EPI, bool SPLIT_DMA, bool PAIR = false, bool STRIP = false, bool LNF = false>
@@ -446,8 +448,16 @@ void launch_gemm_pers(mocr_engine* e, const GemmParams& p, int epi, int blocks, 
                 if (lnf) { launch_gemm_pers_t<EPI_BIAS_RESID, true, true, false, true>(e, p, blocks); return; }
             }
             // the bf16 epilogues on the one-barrier-per-two-K-tiles loop (K64: 64-deep LDS image, whole-line DMA requests)
-            if (epi == EPI_BIAS_GELU && lnf) { launch_gemm_pers_t<EPI_BIAS_GELU, true, true, false, true>(e, p, blocks); return; }
-            if (epi == EPI_BIAS && lnf) { launch_gemm_pers_t<EPI_BIAS, true, true, false, true>(e, p, blocks); return; }
+            if (epi == EPI_BIAS_GELU) {
+                if (strips && lnf) { launch_gemm_pers_t<EPI_BIAS_GELU, true, true, true, true>(e, p, blocks); return; }
+                if (strips) { launch_gemm_pers_t<EPI_BIAS_GELU, true, true, true>(e, p, blocks); return; }
+                if (lnf) { launch_gemm_pers_t<EPI_BIAS_GELU, true, true, false, true>(e, p, blocks); return; }
+            }
+            if (epi == EPI_BIAS) {
+                if (strips && lnf) { launch_gemm_pers_t<EPI_BIAS, true, true, true, true>(e, p, blocks); return; }
+                if (strips) { launch_gemm_pers_t<EPI_BIAS, true, true, true>(e, p, blocks); return; }
+                if (lnf) { launch_gemm_pers_t<EPI_BIAS, true, true, false, true>(e, p, blocks); return; }
+            }
         } else {
             if (epi == EPI_BIAS_RESID && strips) { launch_gemm_pers_t<EPI_BIAS_RESID, true, false, true>(e, p, blocks); return; }
             if (epi == EPI_BIAS_GELU) {
@@ -552,7 +562,7 @@ void gemm(mocr_engine* e, const char* name, const void* A, int lda, const void* 
         // 32-deep K-tile, three K-tiles in flight (r03 first session's choice, when both loops fed on half-line requests)
         static const int pair_bf16 = env_int("MOCR_GEMM_PAIR_BF16", 1);
         if (epi == EPI_BIAS_RESID) launch_gemm_pers<true, true>(e, p, epi, blocks, strip);
-        else if (pair_bf16 && !(strip > 0)) launch_gemm_pers<true, true>(e, p, epi, blocks, 0);
+        else if (pair_bf16) launch_gemm_pers<true, true>(e, p, epi, blocks, strip);
         else launch_gemm_pers<true, false>(e, p, epi, blocks, strip);
     }
 #ifdef MOCR_EXPERIMENTS
@@ -1215,6 +1225,10 @@ template <typename T> void init_kernel_attrs() {
     set_max_lds(gemm_pers_kernel<EPI_BIAS_GELU, true, true>, PERS_LDS);
     set_max_lds(gemm_pers_kernel<EPI_BIAS, true, true, false, true>, PERS_LDS);
     set_max_lds(gemm_pers_kernel<EPI_BIAS_GELU, true, true, false, true>, PERS_LDS);
+    set_max_lds(gemm_pers_kernel<EPI_BIAS, true, true, true, true>, PERS_LDS);
+    set_max_lds(gemm_pers_kernel<EPI_BIAS_GELU, true, true, true, true>, PERS_LDS);
+    set_max_lds(gemm_pers_kernel<EPI_BIAS, true, true, true>, PERS_LDS);
+    set_max_lds(gemm_pers_kernel<EPI_BIAS_GELU, true, true, true>, PERS_LDS);
 #ifdef MOCR_EXPERIMENTS
     set_max_lds(gemm_pers_kernel<EPI_BIAS, false, true>, PERS_LDS);
     set_max_lds(gemm_pers_kernel<EPI_BIAS_GELU, false, true>, PERS_LDS);

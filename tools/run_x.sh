@@ -1,7 +1,8 @@
 #!/bin/bash
-# final r03 numbers: the bench lines kept under profiles/ and the three rocprofv3 passes
 set -o pipefail
-rm -rf gpurun_out/prof_r03b
-bash tools/run_final.sh
-bash tools/profile_passes.sh gpurun_out/prof_r03b > gpurun_out/prof_r03b.log 2>&1; echo "profile rc=$?"
-tail -3 gpurun_out/prof_r03b.log
+O=gpurun_out/r3v
+mkdir -p $O
+timeout -k 10 600 python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "strip or folded_layernorm" > $O/pytest.txt 2>&1; rc=$?; echo "pytest rc=$rc"; tail -3 $O/pytest.txt
+[ $rc -ne 0 ] && exit $rc
+export MOCR_LIB=manga-ocr_amd/manga_ocr/_lib/libmocr_hip_lab.so
+for i in 1 2 3; do timeout -k 10 300 python tools/gemm_bench.py enc 50432 t409 2>&1 | grep -E "fc1" | grep -E "t4096|t4099"; done
