@@ -1,15 +1,7 @@
 #!/bin/bash
 set -o pipefail
-O=gpurun_out/r3x2
-mkdir -p $O
-run() { name=$1; shift; timeout -k 10 300 python bench.py --no-cpu-baseline --no-config4 --no-parity-leg --steps 10 "$@" > $O/$name.json 2> $O/$name.err; python - <<PY
-import json
-d=json.load(open("$O/$name.json"))
-e=d.get("encoder_only") or {}
-print("$name", "value", round(d["value"]), "enc", round(e.get("kernel_ms",0),2), round(e.get("frac_of_mfma_peak",0),4), [(k[0][5:],k[2]) for k in e.get("kernels")][:7])
-PY
-}
-run fold
-run nofold --engine-flags 512
-run fold2
-run nofold2 --engine-flags 512
+timeout -k 10 600 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_parity.py -x -q -m gpu -k "latent" 2>&1 | tail -3
+for i in 1 2; do
+echo "new"; N=2560 LS=100,197,300 timeout -k 10 200 python tools/latent_bench.py 2>&1 | grep "n="
+echo "old"; MOCR_LIB=manga-ocr_amd/manga_ocr/_lib/libmocr_hip_oldlat.so N=2560 LS=100,197,300 timeout -k 10 200 python tools/latent_bench.py 2>&1 | grep "n="
+done
