@@ -1,7 +1,11 @@
 #!/bin/bash
+# End-of-round record on the GPU box: the bench lines kept under profiles/ (tools/run_final.sh) and the three rocprofv3
+# passes (tools/profile_passes.sh).  Back in the build container:
+#   python tools/summarize_profiles.py --round r03 --rows 2560 --stats gpurun_out/prof_r03b/trace \
+#          --fetch gpurun_out/prof_r03b/fetch --write gpurun_out/prof_r03b/write --note "..."
+#   cp gpurun_out/final_r03/bench_*.json profiles/   (as r03_bench_*.json)
 set -o pipefail
-timeout -k 10 600 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_parity.py -x -q -m gpu -k "latent" 2>&1 | tail -3
-for i in 1 2; do
-echo "new"; N=2560 LS=100,197,300 timeout -k 10 200 python tools/latent_bench.py 2>&1 | grep "n="
-echo "old"; MOCR_LIB=manga-ocr_amd/manga_ocr/_lib/libmocr_hip_oldlat.so N=2560 LS=100,197,300 timeout -k 10 200 python tools/latent_bench.py 2>&1 | grep "n="
-done
+rm -rf gpurun_out/prof_r03b
+bash tools/run_final.sh
+bash tools/profile_passes.sh gpurun_out/prof_r03b > gpurun_out/prof_r03b.log 2>&1; echo "profile rc=$?"
+tail -3 gpurun_out/prof_r03b.log
