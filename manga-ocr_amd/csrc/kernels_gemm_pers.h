@@ -455,7 +455,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
         // waves alone - lane l of store wave sw: row 64 sw + l of the tile and column 64 sw + l - and handed to every wave
         // through LDS in the epilogue.  A DMA wave must not load anything in its epilogue: the load queues behind the next
         // tile's K-tiles and its wait holds until they have landed (r03: +2 us per tile).
-        [[maybe_unused]] float4 st_a, st_b;
+        [[maybe_unused]] f32x4 st_a, st_b;
         [[maybe_unused]] float cs_l = 0.f, bias_l = 0.f;
         if constexpr (EPI == EPI_BIAS_RESID) {
             if (!dma_wave) bias_row = *reinterpret_cast<const float4*>(p.bias + n0 + 4 * lane);
@@ -463,10 +463,17 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
             if (!dma_wave) {
                 int m = m0 + 64 * sw + lane;
                 if (guard && m >= p.M) m = p.M - 1;
-                st_a = *reinterpret_cast<const float4*>(p.ln_part + (size_t)m * 8);
-                st_b = *reinterpret_cast<const float4*>(p.ln_part + (size_t)m * 8 + 4);
-                cs_l = p.csum[n0 + 64 * sw + lane];
-                bias_l = p.bias[n0 + 64 * sw + lane];
+                // inline asm: hipcc waits for an ordinary load in a kernel with LDS-DMA in flight at once - vmcnt(0) right behind
+                // the request, a memory round trip in front of every tile's first barrier (r03: QKV +25 us); the wait is in
+                // ln_handover, where the values are used
+                const float* sp = p.ln_part + (size_t)m * 8;
+                const float* cp = p.csum + n0 + 64 * sw + lane;
+                const float* bp = p.bias + n0 + 64 * sw + lane;
+                asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\t"
+                             "global_load_dword %2, %5, off\n\tglobal_load_dword %3, %6, off"
+                             : "=&v"(st_a), "=&v"(st_b), "=&v"(cs_l), "=&v"(bias_l)
+                             : "v"(sp), "v"(cp), "v"(bp)
+                             : "memory");
             }
         } else {
             const float* bsrc = p.bias + n0 + wn * 64 + 4 * g4;
@@ -482,6 +489,9 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
         auto ln_handover = [&]() {
             if constexpr (LNF && EPI != EPI_BIAS_RESID) {
                 if (!dma_wave) {
+                    // the loads requested at the head of the tile have landed long ago; the wait also names their registers,
+                    // so that none of the arithmetic can move above it
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(st_a), "+v"(st_b), "+v"(cs_l), "+v"(bias_l));      // (a store wave: stores + these loads)
                     float* const sst = reinterpret_cast<float*>(smem + RING);
                     const float inv_k = 1.0f / (float)p.k_per_split;
                     const float mean = ((st_a.x + st_a.z) + (st_b.x + st_b.z)) * inv_k;
