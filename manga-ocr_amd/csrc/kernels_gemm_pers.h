@@ -719,6 +719,9 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
                             if (mine && !(ablate & 8)) {
                                 // (non-temporal here measured r03: no difference - 12.74-12.81 against 12.82-13.01 ms for the encoder)
                                 *reinterpret_cast<float4*>(obase + (size_t)row * ldo) = o;
+                                // (r03, measured and dropped: the copy as 16-byte stores, two rows per instruction after a lane-pair
+                                // exchange - O-proj + 29-37 us instead of + 37-41 for the emit in isolation: the copy is bytes, not
+                                // instructions)
                                 if (LNF && !(ablate & 64)) {
                                     uint2 u;
                                     u.x = pack_bf16x2(o.x, o.y); u.y = pack_bf16x2(o.z, o.w);
