@@ -689,8 +689,9 @@ void run_encoder(mocr_engine* e, const uint8_t* d_gray, int n) {
         static const int big_env = env_int("MOCR_ENC_BIG_TILE", 4096);
         // from two tiles per CU (r02 asked for three rounds of one-tile blocks; a persistent block has no turnover to
         // amortise, and at batch 256 the N = 768 GEMMs have 591 tiles)
-        static const int big_rounds = env_int("MOCR_ENC_BIG_ROUNDS", 2);
-        return (sizeof(T) == 2 && tiles >= (long long)big_rounds * e->num_cus) ? big_env : small_tile(N);
+        // (r03, 64-deep image: from 1.7 tiles per CU - QKV of a 64-crop batch, 441 tiles: 64-68 -> 54 us; MOCR_ENC_BIG_ROUNDS x 10)
+        static const int big_rounds10 = env_int("MOCR_ENC_BIG_ROUNDS10", 17);
+        return (sizeof(T) == 2 && tiles * 10 >= (long long)big_rounds10 * e->num_cus) ? big_env : small_tile(N);
     };
     // per-GEMM overrides for experiments: MOCR_ENC_TILE_QKV / _O / _FC1 / _FC2 (tile codes as in gemm())
     static const int tq_env = env_int("MOCR_ENC_TILE_QKV", 0), to_env = env_int("MOCR_ENC_TILE_O", 0),
