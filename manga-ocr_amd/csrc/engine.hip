@@ -691,7 +691,13 @@ void run_encoder(mocr_engine* e, const uint8_t* d_gray, int n) {
         // amortise, and at batch 256 the N = 768 GEMMs have 591 tiles)
         // (r03, 64-deep image: from 1.7 tiles per CU - QKV of a 64-crop batch, 441 tiles: 64-68 -> 54 us; MOCR_ENC_BIG_ROUNDS x 10)
         static const int big_rounds10 = env_int("MOCR_ENC_BIG_ROUNDS10", 17);
-        return (sizeof(T) == 2 && tiles * 10 >= (long long)big_rounds10 * e->num_cus) ? big_env : small_tile(N);
+        // ... and the N = 768 GEMMs also where ONE round of tiles covers half the chip or more (56-111 crops: at 64 crops - 147
+        // tiles - FC2 111 -> 96 us and, all four layer GEMMs then being persistent, the LayerNorm launches go: encoder 4.20 ->
+        // 3.76 ms; at 128 crops - 297 tiles, two rounds for 1.16 - and at 32 - 75 tiles - the 128 x 128 kernel stays ahead)
+        static const int one_round = env_int("MOCR_ENC_ONE_ROUND", 1);
+        const bool big = tiles * 10 >= (long long)big_rounds10 * e->num_cus ||
+                         (one_round && N <= 1024 && tiles * 2 >= e->num_cus && tiles <= e->num_cus);
+        return (sizeof(T) == 2 && big) ? big_env : small_tile(N);
     };
     // per-GEMM overrides for experiments: MOCR_ENC_TILE_QKV / _O / _FC1 / _FC2 (tile codes as in gemm())
     static const int tq_env = env_int("MOCR_ENC_TILE_QKV", 0), to_env = env_int("MOCR_ENC_TILE_O", 0),
