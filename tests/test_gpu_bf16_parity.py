@@ -52,9 +52,12 @@ def first_divergences(got, want, gaps, what):
     return n - len(div), div
 
 
-@pytest.mark.parametrize("rows", [64, 256])
+@pytest.mark.parametrize("rows", [64, 96, 128, 192, 256])
 def test_bf16_auto_path_free_running_ids_against_the_reference(gold, rows):
-    """BASELINE configs[1] (64 rows) and configs[2] (256 rows): the product's automatic kernel choice, max_len 300."""
+    """BASELINE configs[1] (64 rows) and configs[2] (256 rows): the product's automatic kernel choice, max_len 300.  96, 128
+    and 192 rows sit in the other encoder regimes (r03): one round of 256 x 256 tiles for the N = 768 GEMMs with the
+    LayerNorms folded (56-111 crops), the 128 x 128 kernels for them with LayerNorm launches (112-163), two short rounds
+    of the persistent kernel (164-221)."""
     eng = engine("bf16", max_batch=256, auto_path=True)
     gray = crops(777, 256)[:rows]
     ids, lens = eng.recognize(gray)
