@@ -60,6 +60,10 @@ enum {
                                            * step latency there: 50 instead of 80 ms for 64 crops) */
     MOCR_FLAG_NO_SMALL_BATCH_PATH = 1 << 8, /* bf16: batches of <= 32 rows through the generic split-K projections + add/LayerNorm
                                            * launches (28 per decode step) instead of the one-launch-per-projection path (19) */
+    MOCR_FLAG_LATENT_TILE32 = 1 << 10,    /* bf16 latent attention on r03's kernel shape (32-key tiles, one persistent block per CU)
+                                           * instead of 16-key tiles on two blocks per CU: the A/B partner */
+    MOCR_FLAG_NO_COMPACTION = 1 << 11,    /* keep every row of a batch in the decode steps until the whole batch has finished (r01-r03
+                                           * behaviour) instead of compacting the unfinished rows between chunks of steps */
     MOCR_FLAG_NO_LN_FOLD = 1 << 9         /* bf16: the encoder's LayerNorms as launches of their own even where the layer GEMMs run on
                                            * the persistent kernel (default there: folded into the GEMMs on both sides of them) */
 };
@@ -220,6 +224,11 @@ int mocr_op_qqt(mocr_engine* e, const void* d_x, const void* d_wq, const float* 
 
 /* Decode-step HIP graphs this engine holds (test hook: the count must stay bounded whatever row counts callers submit). */
 int mocr_graph_count(mocr_engine* e);
+/* Row compactions this engine has performed (r04): between two chunks of decode steps the unfinished rows of a batch are
+ * moved to the first decode slots and the following steps run on fewer slots - the counterpart of the reference's
+ * one-generate()-per-crop loop, where a short text stops at its own EOS (TF/generation/utils.py:2929-2937 via
+ * src/ui/main_window.py:9801).  Test hook / statistic; MOCR_FLAG_NO_COMPACTION keeps it at 0. */
+int64_t mocr_compaction_count(mocr_engine* e);
 /* Free / total bytes of HBM on a device (the Python constructor sizes its default max_batch from it). */
 int mocr_device_memory(int32_t device, int64_t* free_bytes, int64_t* total_bytes);
 

@@ -128,6 +128,8 @@ struct LaneCtx {
     int* h_pinned = nullptr;                        // [4] pinned: early-exit flags
     // latent attention (bf16): q [Bp,768], Qt / Et [Bp,16,768], per-layer input rows [layers][Bp][max_len][768]
     void *q_t = nullptr, *qt = nullptr, *et = nullptr, *xcache = nullptr;
+    int* rowmap = nullptr;                          // [Bp] decode slot -> row of the batch (identity until the batch is compacted)
+    int* rowmap_tmp = nullptr;                      // [2][Bp] compaction scratch: the new map, and every new slot's old slot
     // fp8 attention: e4m3 copies of the encoder output [Mp][768] and of the per-layer input rows [layers][Bp][max_len][768]
     uint8_t *enc8 = nullptr, *x8cache = nullptr;
 };
@@ -150,7 +152,8 @@ struct Lane {
     bool active = false;
     std::vector<Job> jobs;          // requests merged into this lane's current batch, in row order
     int n = 0, max_len = 0;         // rows of the merged batch, its generate(max_length)
-    int np = 0;                     // rows the decode steps run on: n rounded up (graph_rows), the extra rows are born finished
+    int np = 0;                     // slots the decode steps run on: n rounded up (graph_rows), the extra ones are born finished; shrinks when the batch is compacted
+    int np0 = 0;                    // np at the start of the batch = its kernel regime
     int t = 0, steps = 0, chunk = 0;
     bool flag_pending[2] = {false, false};
     hipEvent_t flag_ev[2] = {nullptr, nullptr};
@@ -167,7 +170,15 @@ struct mocr_engine : LaneCtx {
     bool fp8attn = false;           // latent attention on e4m3 key/value rows + fp8 MFMA (MOCR_FLAG_FP8_ATTENTION, opt-in)
     bool latent = false;            // bf16 engines: latent (absorbed) decode attention ...
     int classic_rows = 0;           // ... for batches of more than this many rows; smaller ones use the classic kernels
+    long long n_compactions = 0;    // batches whose rows were compacted, counted per compaction (mocr_compaction_count)
+    int lat_tk = 16;                // keys per tile of the bf16 latent attention: 16 (two blocks per CU) or 32 (MOCR_FLAG_LATENT_TILE32)
     int Bc = 0;                     // rows the classic K/V buffers are sized for
+    // Kernel regime of the batch being decoded: the row count the batch STARTED with (0: the launch's own row count).
+    // Every choice a decode step makes by row count - attention path, GEMM tile, split-K slabs, fused query kernel,
+    // cache policy - is made by rrows(n), so a batch whose rows were compacted (r04: fewer slots per step as rows finish)
+    // keeps the summation order it started with and a row's ids do not depend on when its neighbours finished.
+    int regime = 0;
+    int rrows(int n) const { return regime > 0 ? regime : n; }
     bool use_latent(int n) const { return latent && n > classic_rows; }
     int smallm_rows = 0;            // bf16: batches of up to this many rows take the one-launch-per-projection path (kernels_smallm.h)
     bool use_smallm(int n) const { return n <= smallm_rows && !use_latent(n); }
@@ -182,7 +193,7 @@ struct mocr_engine : LaneCtx {
     std::vector<Lane> lanes;
     std::vector<Job> pending;
     // decode-step HIP graphs, keyed by (lane, rows, max_len, steps per graph)
-    std::map<std::tuple<int, int, int, int>, hipGraphExec_t> graphs;
+    std::map<std::tuple<int, int, int, int, int>, hipGraphExec_t> graphs;      // + the regime
     void bind(int i) { static_cast<LaneCtx&>(*this) = lanes[i].ctx; }
     void unbind(int i) { lanes[i].ctx = static_cast<LaneCtx&>(*this); }
     // device preprocessing (preprocess.h): resample tables per input size, grow-only scratch
@@ -821,8 +832,8 @@ static int pick_split(int N, int K, int kt, int rows, long long slab_cap_per_row
 template <typename T>
 int dec_gemm(mocr_engine* e, const char* name, const void* A, int lda, const void* W, int N, int K, int rows) {
     const int kt = 128 / (int)sizeof(T);
-    const int split = pick_split(N, K, kt, rows, e->slab_cap / e->Bp);
-    gemm<T>(e, name, A, lda, W, nullptr, e->slabs, N, nullptr, rows, N, K, EPI_SLAB, dec_tile(rows), split, (long long)e->Bp * N);
+    const int split = pick_split(N, K, kt, e->rrows(rows), e->slab_cap / e->Bp);
+    gemm<T>(e, name, A, lda, W, nullptr, e->slabs, N, nullptr, rows, N, K, EPI_SLAB, dec_tile(e->rrows(rows)), split, (long long)e->Bp * N);
     return split;
 }
 
@@ -845,11 +856,11 @@ void dec_add_ln(mocr_engine* e, int nslab, int N, const float* bias, const float
     if (gelu)
         hipLaunchKernelGGL((dec_add_ln_kernel<T, 768, true>), dim3(rows), dim3(192), 0, e->stream, e->slabs, nslab,
                            (long long)e->Bp * N, bias, resid, g, b, out_f32, reinterpret_cast<T*>(out_t), rows, e->cfg.ln_eps,
-                           cache, cstride, (const int*)e->step, cache8, inv8);
+                           cache, cstride, (const int*)e->step, cache8, inv8, (const int*)e->rowmap);
     else
         hipLaunchKernelGGL((dec_add_ln_kernel<T, 768, false>), dim3(rows), dim3(192), 0, e->stream, e->slabs, nslab,
                            (long long)e->Bp * N, bias, resid, g, b, out_f32, reinterpret_cast<T*>(out_t), rows, e->cfg.ln_eps,
-                           cache, cstride, (const int*)e->step, cache8, inv8);
+                           cache, cstride, (const int*)e->step, cache8, inv8, (const int*)e->rowmap);
     HIPCHECK(hipGetLastError());
 }
 
@@ -860,6 +871,7 @@ static DecState make_state(mocr_engine* e, int max_len, const int* forced, int f
     st.forced = forced; st.forced_T = forced_T; st.logits_out = logits_out;
     st.ids_ld = e->cfg.max_len; st.max_len = max_len;
     st.start_id = e->cfg.start_id; st.eos_id = e->cfg.eos_id; st.pad_id = e->cfg.pad_id;
+    st.rowmap = e->rowmap;
     return st;
 }
 
@@ -867,7 +879,7 @@ template <typename T, bool FIRST>
 void dec_token(mocr_engine* e, const DecState& st, int nslab, int n, int ncand = 0) {
     auto& w = e->w;
     ProfScope ps(e, FIRST ? "dec_token_first" : "dec_token", 0, FIRST ? 0.0 : (double)n * e->V * 4 * nslab);
-    const bool lat = e->use_latent(n);
+    const bool lat = e->use_latent(e->rrows(n));
     hipLaunchKernelGGL((dec_token_kernel<T, 768, FIRST>), dim3(n), dim3(256), 0, e->stream, e->slabs, nslab,
                        (long long)e->Bp * e->V, w.bv, e->V, st, w.word, w.type0, w.posd, w.embg, w.embb, e->x_f32,
                        reinterpret_cast<T*>(e->x_t), e->cfg.ln_eps, (lat && !e->fp8attn) ? reinterpret_cast<T*>(e->xcache) : nullptr,
@@ -901,11 +913,12 @@ void dec_attn(mocr_engine* e, int layer, int nslab, int n, const float* bias, in
         p.cross_len = e->S;
     }
     p.ctx = e->ctx_t; p.H = H; p.scale = 0.125f;
+    p.rowmap = e->rowmap;
     // K/V of a 64-row batch (2 layers x 197 keys x 3,072 B = 77 MB + the self cache) live in the Infinity Cache between
     // steps; from about 128 rows they no longer do and the non-temporal policy wins (r02, isolated batch: 256 rows
     // 100.2 -> 91.2 ms, 128 rows 69.1 -> 67.5 ms, 64 rows 49.8 -> 50.8 ms)
     static const int nt_rows = env_int("MOCR_ATTN_NT_ROWS", 128);
-    p.nt = n >= nt_rows;
+    p.nt = e->rrows(n) >= nt_rows;
     ProfScope ps(e, SELF ? "dec_attn_self" : "dec_attn_cross", 4.0 * n * H * approx_len * 64,
                  2.0 * n * H * approx_len * 64 * sizeof(T));
     if (SELF) {
@@ -923,16 +936,33 @@ void dec_attn(mocr_engine* e, int layer, int nslab, int n, const float* bias, in
     HIPCHECK(hipGetLastError());
 }
 
+// The bf16 latent attention launch: 16-key tiles, two persistent blocks per CU (r04; kernels_latent.h) or - MOCR_FLAG_LATENT_TILE32,
+// the A/B partner - r03's 32-key tiles on one block per CU.
+void launch_latent(mocr_engine* e, bool self, const LatentParams& p) {
+    static const int lat_blocks = env_int("MOCR_LAT_BLOCKS", 0);      // persistent blocks (experiments; 0: one or two per CU by tile)
+    const int per_cu = e->lat_tk == 16 ? 2 : 1;
+    const int grid = std::min(p.rows, lat_blocks > 0 ? lat_blocks : per_cu * e->num_cus);
+    if (e->lat_tk == 16) {
+        if (self) hipLaunchKernelGGL((latent_attn_kernel<true, 16>), dim3(grid), dim3(256), LatCfg<16>::LDS, e->stream, p);
+        else hipLaunchKernelGGL((latent_attn_kernel<false, 16>), dim3(grid), dim3(256), LatCfg<16>::LDS, e->stream, p);
+    } else {
+        if (self) hipLaunchKernelGGL((latent_attn_kernel<true, 32>), dim3(grid), dim3(256), LatCfg<32>::LDS, e->stream, p);
+        else hipLaunchKernelGGL((latent_attn_kernel<false, 32>), dim3(grid), dim3(256), LatCfg<32>::LDS, e->stream, p);
+    }
+    HIPCHECK(hipGetLastError());
+}
+
 // Latent attention of n rows: Qt [n,16,768] x keys (self: cached layer-input rows; cross: encoder
 // output) -> Et [n,16,768].  bytes: the X rows streamed once (1,536 B per key).
 void latent_attn(mocr_engine* e, bool self, int layer, int n, int approx_len) {
-    static const int lat_blocks8 = env_int("MOCR_LAT_BLOCKS", 256);
+    static const int lat_blocks8 = env_int("MOCR_LAT_BLOCKS", 0) > 0 ? env_int("MOCR_LAT_BLOCKS", 0) : 256;
     if (e->fp8attn) {
         Latent8Params p{};
         p.qt = reinterpret_cast<const bf16_t*>(e->qt);
         p.out = reinterpret_cast<bf16_t*>(e->et);
         p.heads = e->H;
         p.rows = n;
+        p.rowmap = e->rowmap;
         if (self) {
             p.x8 = e->x8cache + (size_t)layer * e->Bp * e->cfg.max_len * e->D;
             p.x_batch_stride = (long long)e->cfg.max_len * e->D;
@@ -956,6 +986,7 @@ void latent_attn(mocr_engine* e, bool self, int layer, int n, int approx_len) {
     p.out = reinterpret_cast<bf16_t*>(e->et);
     p.heads = e->H;
     p.rows = n;
+    p.rowmap = e->rowmap;
     if (self) {
         p.x = reinterpret_cast<const bf16_t*>(e->xcache) + (size_t)layer * e->Bp * e->cfg.max_len * e->D;
         p.x_batch_stride = (long long)e->cfg.max_len * e->D;
@@ -967,10 +998,7 @@ void latent_attn(mocr_engine* e, bool self, int layer, int n, int approx_len) {
     }
     ProfScope ps(e, self ? "lat_attn_self" : "lat_attn_cross", 4.0 * n * 16 * approx_len * e->D,
                  (double)n * approx_len * e->D * 2 + 2.0 * n * e->H * e->D * 2);     // keys + Qt in + Et out (12 heads)
-    static const int lat_blocks = env_int("MOCR_LAT_BLOCKS", 256);
-    if (self) hipLaunchKernelGGL(latent_attn_kernel<true>, dim3(std::min(n, lat_blocks)), dim3(256), LAT_LDS, e->stream, p);
-    else hipLaunchKernelGGL(latent_attn_kernel<false>, dim3(std::min(n, lat_blocks)), dim3(256), LAT_LDS, e->stream, p);
-    HIPCHECK(hipGetLastError());
+    launch_latent(e, self, p);
 }
 
 // q -> Qt -> latent attention -> ctx: the attention block of the latent path up to (not including)
@@ -982,7 +1010,7 @@ void latent_block(mocr_engine* e, bool self, int layer, int n, int t, const void
     // fat batches: q and Qt in one launch (kernels_qqt.h), 37 us instead of 16 + 31 at 4096 rows; bit-identical to the
     // two-launch path.  MOCR_DEC_QQT_ROWS = rows from which it is used (0 = never)
     static const int qqt_rows = env_int("MOCR_DEC_QQT_ROWS", 1024);
-    if (qqt_rows > 0 && n >= qqt_rows && D == 768 && e->H == 12 && !(e->cfg.flags & MOCR_FLAG_NO_FUSED_QQT)) {
+    if (qqt_rows > 0 && e->rrows(n) >= qqt_rows && D == 768 && e->H == 12 && !(e->cfg.flags & MOCR_FLAG_NO_FUSED_QQT)) {
         QqtParams q{};
         q.x = reinterpret_cast<const bf16_t*>(xin); q.wq = reinterpret_cast<const bf16_t*>(wq); q.bq = bq;
         q.wkT = reinterpret_cast<const bf16_t*>(wkT); q.qt = reinterpret_cast<bf16_t*>(e->qt);
@@ -998,7 +1026,7 @@ void latent_block(mocr_engine* e, bool self, int layer, int n, int t, const void
         return;
     }
     static const int qtile = env_int("MOCR_DEC_QTILE", 64), qttile_env = env_int("MOCR_DEC_QTTILE", 0);
-    const int qttile = qttile_env ? qttile_env : (n >= 1024 ? 128 : 64);      // Qt is output-write bound: fewer, fatter blocks
+    const int qttile = qttile_env ? qttile_env : (e->rrows(n) >= 1024 ? 128 : 64);      // Qt is output-write bound: fewer, fatter blocks
     gemm<T>(e, "gemm_dec_q", xin, D, wq, bq, e->q_t, D, nullptr, n, D, D, EPI_BIAS, qtile, 1);
     HeadBatch hq; hq.heads = e->H; hq.a_yoff = 64; hq.w_yoff = 64; hq.o_yoff = D; hq.b_yoff = 0; hq.ldw = D;
     gemm<T>(e, "gemm_dec_qt", e->q_t, D, wkT, e->w.zero_bias, e->qt, 16 * D, nullptr, n, D, 64, EPI_BIAS, qttile, 1, 0, nullptr, 0, &hq);
@@ -1086,17 +1114,18 @@ void decode_step_smallm(mocr_engine* e, const DecState& st, int n, int t) {
 template <typename T>
 void decode_step(mocr_engine* e, const DecState& st, int n, int t) {
     if constexpr (sizeof(T) == 2) {
-        if (e->use_smallm(n)) { decode_step_smallm(e, st, n, t); return; }
+        if (e->use_smallm(e->rrows(n))) { decode_step_smallm(e, st, n, t); return; }
     }
     const int D = e->D, F = e->F;
     auto& w = e->w;
     const void* xin = e->x_t;
     const float* xres = e->x_f32;
+    const int rn = e->rrows(n);          // the row count the kernel choices are made by (the batch's regime)
     for (int l = 0; l < e->cfg.dec_layers; ++l) {
         const DecLayerW& L = w.dec[l];
         int ns;
         const size_t esz = sizeof(T);
-        if (e->use_latent(n)) {
+        if (e->use_latent(rn)) {
             latent_block(e, true, l, n, t, xin, L.wqkv, L.bqkv, L.wkT_s, reinterpret_cast<const char*>(L.wqkv) + (size_t)2 * D * D * esz,
                          L.bqkv + 2 * D);
         } else {
@@ -1105,7 +1134,7 @@ void decode_step(mocr_engine* e, const DecState& st, int n, int t) {
         }
         ns = dec_gemm<T>(e, "gemm_dec_proj", e->ctx_t, D, L.wo, D, D, n);
         dec_add_ln<T>(e, ns, D, L.bo, xres, L.ln1g, L.ln1b, e->a_f32, e->a_t, n, false);
-        if (e->use_latent(n)) {
+        if (e->use_latent(rn)) {
             latent_block(e, false, l, n, t, e->a_t, L.wqc, L.bqc, L.wkT_c,
                          reinterpret_cast<const char*>(w.wckv) + (size_t)(2 * l + 1) * D * D * esz, w.bckv + (2 * l + 1) * D);
         } else {
@@ -1114,8 +1143,8 @@ void decode_step(mocr_engine* e, const DecState& st, int n, int t) {
         }
         ns = dec_gemm<T>(e, "gemm_dec_proj", e->ctx_t, D, L.woc, D, D, n);
         dec_add_ln<T>(e, ns, D, L.boc, e->a_f32, L.ln2g, L.ln2b, e->c_f32, e->c_t, n, false);
-        if (pick_split(F, D, 128 / (int)sizeof(T), n, e->slab_cap / e->Bp) == 1) {
-            gemm<T>(e, "gemm_dec_fc1", e->c_t, D, L.w1, L.b1, e->h_t, F, nullptr, n, F, D, EPI_BIAS_GELU, dec_tile(n), 1);
+        if (pick_split(F, D, 128 / (int)sizeof(T), rn, e->slab_cap / e->Bp) == 1) {
+            gemm<T>(e, "gemm_dec_fc1", e->c_t, D, L.w1, L.b1, e->h_t, F, nullptr, n, F, D, EPI_BIAS_GELU, dec_tile(rn), 1);
         } else {
             ns = dec_gemm<T>(e, "gemm_dec_fc1", e->c_t, D, L.w1, F, D, n);
             ProfScope ps(e, "dec_bias_gelu", 0, (double)n * F * (4.0 * ns + sizeof(T)));
@@ -1125,7 +1154,7 @@ void decode_step(mocr_engine* e, const DecState& st, int n, int t) {
         }
         ns = dec_gemm<T>(e, "gemm_dec_fc2", e->h_t, F, L.w2, D, F, n);
         dec_add_ln<T>(e, ns, D, L.b2, e->c_f32, L.ln3g, L.ln3b, e->x_f32, e->x_t, n, false,
-                      (e->use_latent(n) && l + 1 < e->cfg.dec_layers) ? l + 1 : -1);
+                      (e->use_latent(rn) && l + 1 < e->cfg.dec_layers) ? l + 1 : -1);
         xin = e->x_t; xres = e->x_f32;
     }
     int ns = dec_gemm<T>(e, "gemm_dec_proj", e->x_t, D, w.wt, D, D, n);
@@ -1133,9 +1162,9 @@ void decode_step(mocr_engine* e, const DecState& st, int n, int t) {
     // LM head.  When the GEMM is not split over K and nobody asked for the logits, its epilogue reduces every N-tile
     // to (max, column) and the token kernel picks among V/tile candidates: the [n, V] fp32 logits (100 MB at 4096
     // rows) are neither written nor read.  acc + bias is the same fp32 value either way, so the argmax is identical.
-    const int vt = dec_tile(n);
+    const int vt = dec_tile(rn);
     if (!st.logits_out && !(e->cfg.flags & MOCR_FLAG_NO_FUSED_ARGMAX) && (vt == 64 || vt == 128) &&
-        pick_split(e->V, D, 128 / (int)sizeof(T), n, e->slab_cap / e->Bp) == 1) {
+        pick_split(e->V, D, 128 / (int)sizeof(T), rn, e->slab_cap / e->Bp) == 1) {
         gemm<T>(e, "gemm_dec_vocab", e->z_t, D, w.wv, w.bv, e->cand_val, e->V, nullptr, n, e->V, D, EPI_ARGMAX, vt, 1, 0, nullptr, 0,
                 nullptr, 0, e->cand_idx);
         dec_token<T, false>(e, st, 1, n, e->V / vt);
@@ -1252,8 +1281,10 @@ template <typename T> void init_kernel_attrs() {
     set_max_lds(smallm_gemm_kernel<SM_PRO_LN, SM_EPI_RAW, 2, 3>, SM_LDS(SM_PRO_LN, 2));
     set_max_lds(smallm_gemm_kernel<SM_PRO_LN, SM_EPI_GELU_BF16, 2, 3>, SM_LDS(SM_PRO_LN, 2));
     set_max_lds(smallm_gemm_kernel<SM_PRO_LN, SM_EPI_GELU_F32, 2, 3>, SM_LDS(SM_PRO_LN, 2));
-    set_max_lds(latent_attn_kernel<true>, LAT_LDS);
-    set_max_lds(latent_attn_kernel<false>, LAT_LDS);
+    set_max_lds(latent_attn_kernel<true, 32>, LatCfg<32>::LDS);
+    set_max_lds(latent_attn_kernel<false, 32>, LatCfg<32>::LDS);
+    set_max_lds(latent_attn_kernel<true, 16>, LatCfg<16>::LDS);
+    set_max_lds(latent_attn_kernel<false, 16>, LatCfg<16>::LDS);
     set_max_lds(latent_attn_fp8_kernel<true>, LAT8_LDS);
     set_max_lds(latent_attn_fp8_kernel<false>, LAT8_LDS);
 }
@@ -1266,7 +1297,7 @@ hipGraphExec_t decode_graph(mocr_engine* e, const DecState& st, int n, int steps
     const int need = ((t0 + steps + 3) / 4 + 7) / 8;
     const int bucket = need <= 3 ? 3 : need <= 5 ? 5 : need <= 8 ? 8 : 10;
     const int t_hi = std::min(bucket * 32, st.max_len) - 1;      // largest context this bucket covers
-    const auto key = std::make_tuple(e->lane_id, n, st.max_len * 16 + bucket, steps);
+    const auto key = std::make_tuple(e->lane_id, n, st.max_len * 16 + bucket, steps, e->rrows(n));
     auto it = e->graphs.find(key);
     if (it != e->graphs.end()) return it->second;
     hipGraph_t g = nullptr;
@@ -1356,7 +1387,7 @@ void start_batch(mocr_engine* e, Lane& L) {
         row0 += j.n;
     }
     run_encoder<T>(e, e->d_in, L.n);
-    if (!e->use_latent(L.np)) run_cross_kv<T>(e, L.n);
+    if (!e->use_latent(L.np0)) run_cross_kv<T>(e, L.n);
     else if (e->fp8attn) quantize_enc(e, L.n);
     // rows read pad_id (= 0) beyond what the loop writes
     HIPCHECK(hipMemsetAsync(e->ids, 0, (size_t)L.np * e->cfg.max_len * sizeof(int), e->stream));
@@ -1380,6 +1411,34 @@ void finish_batch(mocr_engine* e, Lane& L) {
     L.active = false;
 }
 
+// Finished rows stop costing (r04).  `unfinished` is the lane's unfinished-row count as of two chunks ago (the early-exit
+// flag): rows only ever finish, so at most that many are unfinished now.  When the decode steps could run on a smaller
+// graph-friendly row count, the unfinished rows are moved to the first slots (kernels_decode.h: compact_plan_kernel /
+// compact_move_kernel, three small launches between two graph replays) and the next chunks run on that many slots.  The
+// batch keeps its kernel regime (mocr_engine::regime = the row count it started with): the attention paths keep different
+// caches, and with the GEMM tiles and split-K slabs unchanged a row's ids are bit-identical to an uncompacted run's.
+// Worth it from a 1/8 cut: every distinct row count is a decode graph of its own.
+template <typename T>
+void compact_rows(mocr_engine* e, Lane& L, int unfinished) {
+    if (e->cfg.flags & MOCR_FLAG_NO_COMPACTION) return;
+    // (batches of the one-launch-per-projection path - <= 32 rows - stay as they are: their steps are launch-bound)
+    if (e->use_smallm(L.np0)) return;
+    const int want = graph_rows(std::max(unfinished, 1), e->cfg.max_batch);
+    if (want >= L.np || (long long)want * 8 > (long long)L.np * 7) return;
+    ProfScope ps(e, "compact_rows", 0, (double)want * e->D * (4 + sizeof(T)) * 4);
+    int* const new_map = e->rowmap_tmp;
+    int* const src_slot = e->rowmap_tmp + e->Bp;
+    hipLaunchKernelGGL(compact_plan_kernel, dim3(1), dim3(1024), 0, e->stream, (const int*)e->rowmap, (const int*)e->finished, L.np,
+                       new_map, src_slot);
+    for (int phase = 0; phase < 2; ++phase)
+        hipLaunchKernelGGL((compact_move_kernel<T, 768>), dim3(want), dim3(192), 0, e->stream, phase, (const int*)new_map,
+                           (const int*)src_slot, e->x_f32, reinterpret_cast<T*>(e->x_t), e->a_f32, reinterpret_cast<T*>(e->a_t), e->rowmap,
+                           want, L.np);
+    HIPCHECK(hipGetLastError());
+    L.np = want;
+    e->n_compactions += 1;
+}
+
 // Enqueue the next chunk of lane L (or finish it).  Blocks only on a flag two chunks old.
 template <typename T>
 void advance(mocr_engine* e, Lane& L) {
@@ -1389,6 +1448,7 @@ void advance(mocr_engine* e, Lane& L) {
         HIPCHECK(hipEventSynchronize(L.flag_ev[slot]));
         L.flag_pending[slot] = false;
         if (e->h_pinned[slot] <= 0) { finish_batch(e, L); return; }
+        if (e->D == 768) compact_rows<T>(e, L, e->h_pinned[slot]);
     }
     if (L.t >= L.steps) { finish_batch(e, L); return; }
     DecState st = make_state(e, L.max_len, nullptr, 0, nullptr, L.n);
@@ -1447,15 +1507,19 @@ bool pump_once(mocr_engine* e) {
                 ++take;
             }
             e->pending.erase(e->pending.begin(), e->pending.begin() + take);
-            L.np = graph_rows(L.n, e->cfg.max_batch);
+            L.np = L.np0 = graph_rows(L.n, e->cfg.max_batch);
             L.active = true;
             e->bind((int)i);
+            e->regime = L.np0;
             start_batch<T>(e, L);
+            e->regime = 0;
             e->unbind((int)i);
         }
         if (L.active) {
             e->bind((int)i);
+            e->regime = L.np0;
             advance<T>(e, L);
+            e->regime = 0;
             e->unbind((int)i);
             any = true;
         }
@@ -1469,6 +1533,7 @@ void drive(mocr_engine* e) {
         if (e->cfg.dtype == MOCR_BF16) { while (pump_once<bf16_t>(e)) {} }
         else { while (pump_once<float>(e)) {} }
     } catch (...) {
+        e->regime = 0;
         e->pending.clear();
         for (auto& L : e->lanes) { L.active = false; L.jobs.clear(); (void)hipStreamSynchronize(L.ctx.stream); }
         throw;
@@ -1736,6 +1801,7 @@ void allocate_lane(mocr_engine* e, int lane_id) {
     e->h_t = e->dalloc<char>(Bp * (size_t)e->F * esz);
     e->ids = e->dalloc<int>(Bp * (size_t)c.max_len);
     e->step = e->dalloc<int>(Bp); e->finished = e->dalloc<int>(Bp); e->len = e->dalloc<int>(Bp); e->n_unf = e->dalloc<int>(4);
+    e->rowmap = e->dalloc<int>(Bp); e->rowmap_tmp = e->dalloc<int>(2 * Bp);
     HIPCHECK(hipHostMalloc(reinterpret_cast<void**>(&e->h_pinned), 64, hipHostMallocDefault));
 }
 
@@ -1743,6 +1809,7 @@ void allocate_lanes(mocr_engine* e) {
     compute_geometry(e);
     e->latent = e->cfg.dtype == MOCR_BF16 && !(e->cfg.flags & MOCR_FLAG_CLASSIC_ATTENTION);
     e->fp8attn = e->latent && (e->cfg.flags & MOCR_FLAG_FP8_ATTENTION);
+    e->lat_tk = (e->cfg.flags & MOCR_FLAG_LATENT_TILE32) ? 32 : env_int("MOCR_LAT_TK", 16);
     // Small batches of a latent engine take the classic kernels: the persistent latent kernel walks a sequence's key
     // tiles serially on ONE CU (~20 us per call whatever the batch), the classic one spreads a row over 12 blocks.
     // Measured (r01, 300 tokens): 8 rows 36 vs 73 ms, 64 rows 50 vs 80 ms, 256 rows 111 vs 116 ms; r02, both paths with
@@ -2268,6 +2335,12 @@ int mocr_set_generate_max_length(mocr_engine* e, int32_t max_len) {
     });
 }
 
+int64_t mocr_compaction_count(mocr_engine* e) {
+    if (!e) return 0;
+    std::lock_guard<std::mutex> lk(e->mu);
+    return e->n_compactions;
+}
+
 int mocr_graph_count(mocr_engine* e) {
     if (!e) return MOCR_ERR_ARG;
     std::lock_guard<std::mutex> lk(e->mu);
@@ -2417,8 +2490,7 @@ int mocr_op_latent_attention(mocr_engine* e, const void* d_qt, const void* d_x, 
         static unsigned long long* dbg = nullptr;
         if (env_int("MOCR_LAT_STAMP", 0)) { if (!dbg) dbg = e->dalloc<unsigned long long>(8 + 512); p.dbg = dbg; }
         ProfScope ps(e, "op_latent", 0, (double)n * len * 1536);
-        hipLaunchKernelGGL(latent_attn_kernel<false>, dim3(std::min((int)n, env_int("MOCR_LAT_BLOCKS", 256))), dim3(256), LAT_LDS, e->stream, p);
-        HIPCHECK(hipGetLastError());
+        launch_latent(e, false, p);
         HIPCHECK(hipStreamSynchronize(e->stream));
         if (p.dbg) {
             unsigned long long h[8];

@@ -478,6 +478,7 @@ struct DecAttnParams {
     int H;
     float scale;
     int nt;                  // stream the K/V rows with the non-temporal policy (batches whose K/V outgrow the Infinity Cache)
+    const int* rowmap;       // decode slot -> row of the batch whose K/V it attends to (identity until a batch is compacted); null: identity
 };
 
 // raw 8-element row chunk: 16 B in bf16, 32 B in fp32; loads issue without being consumed
@@ -536,8 +537,9 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(DecAttnParams p) {
     per = (per + 7) & ~7;
     const int k_begin = wave * per;
     const int k_end = min(Lc, k_begin + per);
-    const T* kb = reinterpret_cast<const T*>(p.kbase) + (size_t)b * p.kv_batch_stride + (size_t)h * p.kv_head_stride + c * 8;
-    const T* vb = reinterpret_cast<const T*>(p.vbase) + (size_t)b * p.kv_batch_stride + (size_t)h * p.kv_head_stride + c * 8;
+    const int br = p.rowmap ? p.rowmap[b] : b;             // K/V caches and cross K/V stay where the row was encoded
+    const T* kb = reinterpret_cast<const T*>(p.kbase) + (size_t)br * p.kv_batch_stride + (size_t)h * p.kv_head_stride + c * 8;
+    const T* vb = reinterpret_cast<const T*>(p.vbase) + (size_t)br * p.kv_batch_stride + (size_t)h * p.kv_head_stride + c * 8;
 
     // ---- issue every K/V load of this wave (clamped rows are valid addresses and get weight 0)
     raw8<T> kr[NG], vr[NG];

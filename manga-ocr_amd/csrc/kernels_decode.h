@@ -17,7 +17,7 @@ __global__ __launch_bounds__(D / 4) void dec_add_ln_kernel(const float* __restri
                                                            float* __restrict__ out_f32, T* __restrict__ out_t, int rows, float eps,
                                                            T* __restrict__ cache = nullptr, long long cache_batch_stride = 0,
                                                            const int* __restrict__ step = nullptr, uint8_t* __restrict__ cache8 = nullptr,
-                                                           float inv_sx8 = 0.f) {
+                                                           float inv_sx8 = 0.f, const int* __restrict__ rowmap = nullptr) {
     constexpr int NW = D / 256;                      // waves per block
     __shared__ float s_red[2][NW];
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -68,10 +68,11 @@ __global__ __launch_bounds__(D / 4) void dec_add_ln_kernel(const float* __restri
     if (out_f32) *reinterpret_cast<float4*>(out_f32 + (size_t)row * D + c) = make_float4(o[0], o[1], o[2], o[3]);
     elem<T>::st4(out_t + (size_t)row * D + c, o);
     // latent attention: this row is also the key/value source of position step[row] for the next layer
-    if (cache) elem<T>::st4(cache + (size_t)row * cache_batch_stride + (size_t)step[row] * D + c, o);
+    const int crow = rowmap ? rowmap[row] : row;     // the per-row caches stay where the row started (compacted batches)
+    if (cache) elem<T>::st4(cache + (size_t)crow * cache_batch_stride + (size_t)step[row] * D + c, o);
     // fp8 attention mode: the same row as e4m3 bytes with the cache's static scale (kernels_latent8.h)
     if (cache8)
-        *reinterpret_cast<unsigned*>(cache8 + (size_t)row * cache_batch_stride + (size_t)step[row] * D + c) =
+        *reinterpret_cast<unsigned*>(cache8 + (size_t)crow * cache_batch_stride + (size_t)step[row] * D + c) =
             pack4_fp8(o[0] * inv_sx8, o[1] * inv_sx8, o[2] * inv_sx8, o[3] * inv_sx8);
 }
 
@@ -114,6 +115,12 @@ struct DecState {
     int max_len;       // generate(max_length): a row is finished when it holds max_len tokens
     int start_id, eos_id, pad_id;
     int n_real;        // rows >= n_real are padding (the batch is rounded up to a graph-friendly row count): born finished
+    // Decode SLOT -> ROW of the batch (r04).  ids / finished / len and the per-row key/value caches are indexed by row and
+    // never move; the activations of a step (x, slabs, ...) and `step` are indexed by slot.  Identity from the start token
+    // on; compact_rows (engine.hip) rewrites it so that the unfinished rows occupy the first slots and the decode steps
+    // can run on fewer of them - a finished row stops costing, as in the reference, where every crop is its own
+    // generate() call (TF/generation/utils.py:2929-2937, src/core/workers.py:213-225).
+    int* rowmap;
 };
 
 // End of a decode step, one block per sequence:
@@ -138,8 +145,10 @@ __global__ __launch_bounds__(256) void dec_token_kernel(const float* __restrict_
     __shared__ float s_red[4];
     __shared__ int s_tok, s_pos;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row = FIRST ? b : st.rowmap[b];       // slot b decodes row `row` of the batch
     if (FIRST) {
         if (tid == 0) {
+            st.rowmap[b] = b;
             st.ids[(size_t)b * st.ids_ld] = st.start_id;
             st.step[b] = 0; st.finished[b] = b >= st.n_real ? 1 : 0; st.len[b] = st.max_len;
             s_tok = st.start_id; s_pos = 0;
@@ -192,13 +201,13 @@ __global__ __launch_bounds__(256) void dec_token_kernel(const float* __restrict_
             for (int w = 1; w < 4; ++w)
                 if (s_val[w] > best || (s_val[w] == best && s_idx[w] < bi)) { best = s_val[w]; bi = s_idx[w]; }
             if ((unsigned)bi >= (unsigned)V) bi = 0;      // all-NaN logits win no comparison: stay inside the embedding table
-            int fin = st.finished[b];
+            int fin = st.finished[row];
             int tok = fin ? st.pad_id : bi;
             if (st.forced) tok = (t + 1 < st.forced_T) ? st.forced[(size_t)b * st.forced_T + t + 1] : st.pad_id;
-            if (t + 1 < st.ids_ld) st.ids[(size_t)b * st.ids_ld + t + 1] = tok;
+            if (t + 1 < st.ids_ld) st.ids[(size_t)row * st.ids_ld + t + 1] = tok;
             if (!fin && !st.forced && (tok == st.eos_id || t + 2 >= st.max_len)) {
-                st.finished[b] = 1;
-                st.len[b] = t + 2;
+                st.finished[row] = 1;
+                st.len[row] = t + 2;
                 atomicSub(st.n_unfinished, 1);
             }
             st.step[b] = t + 1;
@@ -236,7 +245,67 @@ __global__ __launch_bounds__(256) void dec_token_kernel(const float* __restrict_
         const float o = (v[i] - mean) * rstd * gamma[d] + beta[d];
         x_f32[(size_t)b * D + d] = o;
         elem<T>::st(x_t + (size_t)b * D + d, o);
-        if (cache) elem<T>::st(cache + (size_t)b * cache_batch_stride + (size_t)ps * D + d, o);   // layer-0 key/value source
-        if (cache8) cache8[(size_t)b * cache_batch_stride + (size_t)ps * D + d] = (uint8_t)(pack4_fp8(o * inv_sx8, 0.f, 0.f, 0.f) & 0xff);
+        if (cache) elem<T>::st(cache + (size_t)row * cache_batch_stride + (size_t)ps * D + d, o);   // layer-0 key/value source
+        if (cache8) cache8[(size_t)row * cache_batch_stride + (size_t)ps * D + d] = (uint8_t)(pack4_fp8(o * inv_sx8, 0.f, 0.f, 0.f) & 0xff);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row compaction (r04): finished rows stop costing.
+// In the reference every crop is its own generate() call and stops at its own EOS (TF/generation/utils.py:2929-2937,
+// called per crop at src/ui/main_window.py:9801).  A merged batch decodes in lockstep; between two chunks of steps the
+// scheduler (engine.hip: compact_rows) moves the unfinished rows to the first slots and lets the next chunk run on fewer
+// slots.  Only the step's input rows (x_f32 / x_t) move: ids, finished, len and every key/value cache are indexed by ROW
+// through DecState::rowmap and stay where they are.
+//
+// compact_plan_kernel, ONE block: stable partition of the np slots by "row unfinished" -> new_map[s'] = row of new slot
+// s', src_slot[s'] = the slot it comes from.  The finished rows fill the slots behind the live ones (any slot the next
+// chunks still run - the row count is rounded up to a graph-friendly grid - then holds a finished row: it emits pad_id
+// into that row's tail, which is what an uncompacted batch does to it).
+__global__ __launch_bounds__(1024) void compact_plan_kernel(const int* __restrict__ rowmap, const int* __restrict__ finished, int np,
+                                                            int* __restrict__ new_map, int* __restrict__ src_slot) {
+    __shared__ int s_cnt[1024];
+    const int tid = threadIdx.x;
+    const int per = (np + 1023) / 1024, s0 = tid * per, s1 = min(np, s0 + per);
+    int live = 0;
+    for (int s = s0; s < s1; ++s) live += finished[rowmap[s]] ? 0 : 1;
+    s_cnt[tid] = live;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {          // inclusive scan
+        const int v = tid >= off ? s_cnt[tid - off] : 0;
+        __syncthreads();
+        s_cnt[tid] += v;
+        __syncthreads();
+    }
+    const int n_live = s_cnt[1023];
+    int pl = s_cnt[tid] - live;                          // live slots in front of s0
+    for (int s = s0; s < s1; ++s) {
+        const int row = rowmap[s];
+        const bool lv = !finished[row];
+        const int dst = lv ? pl : n_live + (s - pl);
+        new_map[dst] = row; src_slot[dst] = s;
+        pl += lv ? 1 : 0;
+    }
+}
+
+// phase 0: tmp[s'] = x[src_slot[s']] for the np_new slots that stay; phase 1: x[s'] = tmp[s'], rowmap = new_map (np_old entries).
+// One block of D/4 threads per slot.
+template <typename T, int D>
+__global__ __launch_bounds__(D / 4) void compact_move_kernel(int phase, const int* __restrict__ new_map, const int* __restrict__ src_slot,
+                                                              float* __restrict__ x_f32, T* __restrict__ x_t, float* __restrict__ tmp_f32,
+                                                              T* __restrict__ tmp_t, int* __restrict__ rowmap, int np_new, int np_old) {
+    const int s = blockIdx.x, c = threadIdx.x * 4;
+    if (phase == 0) {
+        const int src = src_slot[s];
+        *reinterpret_cast<float4*>(tmp_f32 + (size_t)s * D + c) = *reinterpret_cast<const float4*>(x_f32 + (size_t)src * D + c);
+        float v[4];
+        elem<T>::ld4(x_t + (size_t)src * D + c, v);
+        elem<T>::st4(tmp_t + (size_t)s * D + c, v);
+    } else {
+        *reinterpret_cast<float4*>(x_f32 + (size_t)s * D + c) = *reinterpret_cast<const float4*>(tmp_f32 + (size_t)s * D + c);
+        float v[4];
+        elem<T>::ld4(tmp_t + (size_t)s * D + c, v);
+        elem<T>::st4(x_t + (size_t)s * D + c, v);
+        for (int i = s * (D / 4) + threadIdx.x; i < np_old; i += gridDim.x * (D / 4)) rowmap[i] = new_map[i];
     }
 }

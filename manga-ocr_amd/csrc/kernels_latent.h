@@ -28,7 +28,7 @@
 #define LAT_TILE_BYTES (LAT_TK * LAT_D * 2)
 #define LAT_NST 3
 #define LAT_OUT_HS (LAT_D * 2 + 16)   // head-row stride of the output staging image
-#define LAT_LDS (LAT_NST * LAT_TILE_BYTES + 4 * 16 * 32 * 4 + 4 * 16 * 32 * 2)
+#define LAT_LDS (LAT_NST * LAT_TILE_BYTES + 4 * 16 * 32 * 4 + 4 * 16 * 32 * 2)     // TK = 32; LatCfg<TK>::LDS in general
 
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 
@@ -37,6 +37,7 @@ struct LatentParams {
     const bf16_t* x;            // keys: row-major [.., 768]
     bf16_t* out;                // [rows][16][768]  sum_key p * X[key]   (heads 12..15 not written)
     long long x_batch_stride;   // elements between two sequences' first key
+    const int* rowmap;          // null: sequence r reads slot r of x; else (compacted batches, r04) slot rowmap[r]
     const int* step;            // self: context length = step[0] + 1 for EVERY row (a batch decodes in lockstep); null: fixed_len
     int fixed_len;
     int heads;                  // 12
@@ -96,6 +97,15 @@ __device__ __forceinline__ void lds_read12_b128(uint4* o, const unsigned* a) {
           "v"(a[10]), "v"(a[11])
         : "memory");
 }
+__device__ __forceinline__ void lds_read6_b128(uint4* o, const unsigned* a) {
+    asm volatile(
+        "ds_read_b128 %0, %6\n\tds_read_b128 %1, %7\n\tds_read_b128 %2, %8\n\tds_read_b128 %3, %9\n\t"
+        "ds_read_b128 %4, %10\n\tds_read_b128 %5, %11\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5])
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5])
+        : "memory");
+}
 __device__ __forceinline__ void tr_read12(uint2* o, const unsigned* a) {
     asm volatile(
         "ds_read_b64_tr_b16 %0, %12\n\tds_read_b64_tr_b16 %1, %13\n\tds_read_b64_tr_b16 %2, %14\n\t"
@@ -112,6 +122,10 @@ __device__ __forceinline__ void tr_read12(uint2* o, const unsigned* a) {
 __device__ __forceinline__ void lds_read2_b128(uint4* o, unsigned a0, unsigned a1) {
     asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
                  : "=&v"(o[0]), "=&v"(o[1]) : "v"(a0), "v"(a1) : "memory");
+}
+__device__ __forceinline__ void lds_read_b128_b64(uint4& o0, uint2& o1, unsigned a0, unsigned a1) {
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b64 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(o0), "=&v"(o1) : "v"(a0), "v"(a1) : "memory");
 }
 __device__ __forceinline__ void lds_read3_b128(uint4* o, unsigned a0, unsigned a1, unsigned a2) {
     asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %4\n\tds_read_b128 %2, %5\n\ts_waitcnt lgkmcnt(0)"
@@ -163,18 +177,43 @@ __device__ __forceinline__ void wait_vm_newer(int newer) {
 // tile image) with pc < np.  A full tile is np = 48 pieces (16 DMA instructions per DMA wave); a sequence's last tile
 // asks only for the pieces that hold its valid keys (src_off: this lane's 16 source offsets).  The branch is
 // wave-uniform; the caller adds lat_pieces_of(np, w) to its load count.
-template <int I0 = 0, int I1 = 16>
-__device__ __forceinline__ void lat_stage(const char* src, char* dst, const unsigned (&src_off)[16], int w, int np) {
+template <int I0, int I1, int NPW>
+__device__ __forceinline__ void lat_stage(const char* src, char* dst, const unsigned (&src_off)[NPW], int w, int np) {
 #pragma unroll
     for (int i = I0; i < I1; ++i)
         if (w + 3 * i < np) LAT_GLDS(src + src_off[i], dst + (w + 3 * i) * 1024);
 }
-__device__ __forceinline__ int lat_pieces_of(int np, int w) { return (np - w + 2) / 3; }   // #i in 0..15 with w+3i < np (np <= 48)
+__device__ __forceinline__ int lat_pieces_of(int np, int w) { return (np - w + 2) / 3; }   // #i in 0..NPW-1 with w+3i < np (np <= 3 NPW)
 
 // SELF only names the instantiation (self: context = step[0] + 1 keys of the per-token cache; cross: the fixed 197
 // encoder rows), so that profiles list the two launches of a decode layer as two kernels.
-template <bool SELF>
-__global__ __launch_bounds__(256, 1) void latent_attn_kernel(LatentParams p) {
+//
+// TK = keys per tile (r04).  TK = 32: one block per CU, 48-KiB tiles, 156 KiB of LDS (r01-r03).  TK = 16: 24-KiB tiles, 78
+// KiB of LDS and at most 256 registers, so that TWO blocks share a CU: tools/probe/stream_probe.hip (r03) showed that the
+// memory system delivers this byte stream at 0.88-0.91 of the HBM peak while the one-block kernel takes 0.62 - its
+// per-tile chain (wait, barrier, score MFMAs, exchange through LDS, barrier, softmax, barrier, P.X) runs on ONE wave per
+// SIMD with nothing to fill its gaps.  With two co-resident blocks the second block's waves are that filler: each block
+// keeps its own ring, its own barriers and its own request bookkeeping (nothing is shared, nothing new to count), and
+// the hardware interleaves the two chains.  A 16-key tile is one 16-key score sub-tile and, for P.X, one
+// v_mfma_f32_16x16x16_bf16 per column tile (K = 16 keys: one transposed block read each); the 197 cross keys are 13
+// tiles with 11 keys of padding work instead of 7 tiles with 27.
+template <int TK> struct LatCfg {
+    static_assert(TK == 16 || TK == 32, "key tile");
+    static constexpr int TILE_BYTES = TK * LAT_D * 2;
+    static constexpr int NPW = TK / 2;               // 1-KiB pieces a DMA wave requests per full tile
+    static constexpr int NP = 3 * NPW;               // pieces of a full tile
+    static constexpr int J = TK / 16;                // 16-key score sub-tiles
+    static constexpr int LDS = LAT_NST * TILE_BYTES + 4 * 16 * TK * 4 + 4 * 16 * TK * 2;
+    static constexpr int BLOCKS_PER_CU = TK == 16 ? 2 : 1;
+    // the tile's request in three parts (behind the top, the score and the probability barrier)
+    static constexpr int I1 = TK == 32 ? 6 : 3, I2 = TK == 32 ? 11 : 6;
+};
+typedef short lat_s16x4 __attribute__((ext_vector_type(4)));
+
+template <bool SELF, int TK = 32>
+__global__ __launch_bounds__(256, LatCfg<TK>::BLOCKS_PER_CU) void latent_attn_kernel(LatentParams p) {
+    using C = LatCfg<TK>;
+    constexpr int TILE_BYTES = C::TILE_BYTES, NPW = C::NPW, NP = C::NP, J = C::J;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // plain locals: the lambdas below must not take the address of the kernel-argument struct (that
     // would push it to scratch, and scratch traffic is VMEM traffic the bookkeeping does not count)
@@ -182,6 +221,7 @@ __global__ __launch_bounds__(256, 1) void latent_attn_kernel(LatentParams p) {
     const bf16_t* const P_x = p.x;
     bf16_t* const P_out = p.out;
     const long long P_xstride = p.x_batch_stride;
+    const int* const P_rowmap = p.rowmap;
     const int P_rows = p.rows, P_heads = p.heads;
     // Diagnostic cycle stamps (s_memtime) are compiled in only with -DMOCR_LAT_STAMPS: a runtime
     // "if (dbg)" branch right behind an MFMA chain jumps over the compiler's hazard padding
@@ -201,43 +241,43 @@ __global__ __launch_bounds__(256, 1) void latent_attn_kernel(LatentParams p) {
 #else
 #define STAMP(k)
 #endif
-    float* sS = reinterpret_cast<float*>(smem + LAT_NST * LAT_TILE_BYTES);        // [4][16][32] partial scores
-    bf16_t* sP = reinterpret_cast<bf16_t*>(sS + 4 * 16 * 32);                      // [16][32] probabilities (1 KiB of a 4 KiB area)
-    float* sAl = reinterpret_cast<float*>(sP + 16 * 32);                           // [16] per-head rescale factors, then [16] row sums
+    float* sS = reinterpret_cast<float*>(smem + LAT_NST * TILE_BYTES);             // [4][16][TK] partial scores
+    bf16_t* sP = reinterpret_cast<bf16_t*>(sS + 4 * 16 * TK);                      // [16][TK] probabilities (a quarter of its area)
+    float* sAl = reinterpret_cast<float*>(sP + 16 * TK);                           // [16] per-head rescale factors, then [16] row sums
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     const int nblk = gridDim.x;
     // one context length for the whole launch, read ONCE before any DMA is in flight (an ordinary load
     // later would make the compiler drain the ring)
     const int L = p.step ? p.step[0] + 1 : p.fixed_len /* before any lambda */;
-    const int ntile = (L + LAT_TK - 1) / LAT_TK;
+    const int ntile = (L + TK - 1) / TK;
 
-    // DMA source offsets of this lane for the 12 pieces a wave copies per tile: piece pc covers the
+    // DMA source offsets of this lane for the NPW pieces a wave copies per tile: piece pc covers the
     // linear 16-byte chunks 64*pc .. 64*pc+63 of the tile image
-    unsigned src_off[16];
+    unsigned src_off[NPW];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int gch = 64 * ((wave < 3 ? wave : 0) + 3 * i) + lane;      // 0 .. 3071 (wave 3 requests nothing)
+    for (int i = 0; i < NPW; ++i) {
+        const int gch = 64 * ((wave < 3 ? wave : 0) + 3 * i) + lane;      // 0 .. 96 TK - 1 (wave 3 requests nothing)
         const int r = gch / 96, cp = gch - r * 96;       // key row, physical chunk
         const int c = (cp & ~15) | ((cp ^ r) & 15);      // logical chunk stored there
         src_off[i] = (unsigned)(r * (LAT_D * 2) + c * 16);
     }
-    // byte offsets (inside a tile image) of this lane's transposed block reads for keys 8g .. 8g+3, one
-    // per column tile; the block of keys 8g+4 .. 8g+7 is 4 rows further with chunk bit 2 flipped by the
-    // swizzle: (off + 4 * 1536) ^ 64
+    // byte offsets (inside a tile image) of this lane's transposed block reads, one per column tile.
+    // TK = 32 (K = 32 MFMA: keys 8g .. 8g+7 per lane group): the block of keys 8g .. 8g+3; the block of keys 8g+4 .. 8g+7 is
+    // 4 rows further with chunk bit 2 flipped by the swizzle: (off + 4 * 1536) ^ 64.  TK = 16 (K = 16 MFMA): keys 4g .. 4g+3.
     unsigned tr_off[12];
     {
-        const int q4 = l15 >> 2, p4 = l15 & 3, r0 = 8 * g + q4;
+        const int q4 = l15 >> 2, p4 = l15 & 3, r0 = (TK == 32 ? 8 : 4) * g + q4;
 #pragma unroll
         for (int dt = 0; dt < 12; ++dt) {
             const int c = ((192 * wave + 16 * dt) >> 3) + (p4 >> 1);
             tr_off[dt] = lat_off(r0, c) + 8 * (p4 & 1);
         }
     }
-    // byte offsets (inside a tile image) of this lane's 12 row reads of the S product: [sub-tile j][k-step s]
-    unsigned s_off[12];
+    // byte offsets (inside a tile image) of this lane's row reads of the S product: [sub-tile j][k-step s]
+    unsigned s_off[6 * J];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < J; ++j)
 #pragma unroll
         for (int s = 0; s < 6; ++s) s_off[6 * j + s] = lat_off(16 * j + l15, 24 * wave + 4 * s + g);
     const unsigned smem_base = lds_addr(smem);
@@ -246,6 +286,8 @@ __global__ __launch_bounds__(256, 1) void latent_attn_kernel(LatentParams p) {
     // traffic - and their results are never stored)
     const bf16_t* const q_lane = P_qt + (size_t)(l15 < P_heads ? l15 : l15 - P_heads) * LAT_D + 192 * wave + 8 * g;
 #define Q_PTR(row) (q_lane + (size_t)(row) * 16 * LAT_D)
+    // keys of sequence `row`: its own slot of x, or (r04, compacted batches) the slot its rowmap entry names
+#define X_ROW(row) (P_x + (size_t)(P_rowmap ? P_rowmap[row] : (row)) * P_xstride)
 
     int cr = blockIdx.x;                 // sequence being consumed
     if (cr >= P_rows) return;
@@ -259,27 +301,34 @@ __global__ __launch_bounds__(256, 1) void latent_attn_kernel(LatentParams p) {
     int mk0 = 0, mk1 = 0, mk2 = 0;       // `issued` right after the tile of ring slot 0/1/2 was requested
     // issue side of the ring: next (sequence, tile) to request and the slot it goes to
     int ir = cr, it = 0, islot = 0;
+    const bf16_t* ix = X_ROW(cr);        // key rows of sequence `ir` (a wave-uniform, i.e. scalar, rowmap load: no VMEM)
+#define ISSUE_ADVANCE_ROW()                                                                                       \
+    do {                                                                                                          \
+        ir += nblk; it = 0;                                                                                       \
+        if (ir < P_rows) ix = X_ROW(ir);                                                                          \
+    } while (0)
 #define ISSUE_NEXT()                                                                                              \
     do {                                                                                                          \
         if (ir < P_rows) {                                                                                        \
-            const int np_ = it == cnt - 1 ? np_last : 48;                                                         \
+            const int np_ = it == cnt - 1 ? np_last : NP;                                                         \
             if (wave < 3) {                                                                                       \
-                lat_stage(reinterpret_cast<const char*>(P_x + (size_t)ir * P_xstride) + (size_t)it * LAT_TILE_BYTES, \
-                          smem + islot * LAT_TILE_BYTES, src_off, wave, np_);                                     \
+                lat_stage<0, NPW, NPW>(reinterpret_cast<const char*>(ix) + (size_t)it * TILE_BYTES,                \
+                                       smem + islot * TILE_BYTES, src_off, wave, np_);                            \
                 issued += lat_pieces_of(np_, wave);                                                               \
             }                                                                                                     \
             if (islot == 0) mk0 = issued; else if (islot == 1) mk1 = issued; else mk2 = issued;                   \
             islot = islot + 1 == LAT_NST ? 0 : islot + 1;                                                         \
-            if (++it == cnt) { ir += nblk; it = 0; }                                                              \
+            if (++it == cnt) ISSUE_ADVANCE_ROW();                                                                 \
         }                                                                                                         \
     } while (0)
     // The same request spread over the three phases of an iteration (r02): a DMA wave's 16 pieces cost it 60-185 cycles
     // of issue each, and issued as one burst behind the top barrier they delayed the wave's own score phase - and with
     // it the block's next barrier.  The slot being refilled is read by nobody during the whole iteration, so pieces
     // 0-5 go out behind the top barrier, 6-10 behind the score barrier (the softmax phase is short and latency-bound)
-    // and 11-15 behind the probability barrier; the bookkeeping (load count, slot mark, ring position) is done once,
-    // with the last part.  Cross launch at 2560 rows: 193.6 -> 182.7 us.  (Moving ALL the DMA issue to two extra
-    // loader waves - a six-wave block - was also built and measured: 183.9 us, i.e. nothing more; removed.)
+    // and 11-15 behind the probability barrier (TK = 16: 0-2, 3-5, 6-7); the bookkeeping (load count, slot mark, ring
+    // position) is done once, with the last part.  Cross launch at 2560 rows: 193.6 -> 182.7 us.  (Moving ALL the DMA
+    // issue to two extra loader waves - a six-wave block - was also built and measured: 183.9 us, i.e. nothing more;
+    // removed.)
     const char* is_src = nullptr;
     char* is_dst = nullptr;
     int is_np = 0;
@@ -287,14 +336,14 @@ __global__ __launch_bounds__(256, 1) void latent_attn_kernel(LatentParams p) {
     do {                                                                                                          \
         is_np = 0;                                                                                                \
         if (ir < P_rows) {                                                                                        \
-            is_np = it == cnt - 1 ? np_last : 48;                                                                 \
-            is_src = reinterpret_cast<const char*>(P_x + (size_t)ir * P_xstride) + (size_t)it * LAT_TILE_BYTES;    \
-            is_dst = smem + islot * LAT_TILE_BYTES;                                                               \
+            is_np = it == cnt - 1 ? np_last : NP;                                                                 \
+            is_src = reinterpret_cast<const char*>(ix) + (size_t)it * TILE_BYTES;                                  \
+            is_dst = smem + islot * TILE_BYTES;                                                                   \
         }                                                                                                         \
     } while (0)
 #define ISSUE_PART(I0, I1)                                                                                        \
     do {                                                                                                          \
-        if (is_np > 0 && wave < 3) lat_stage<I0, I1>(is_src, is_dst, src_off, wave, is_np);                       \
+        if (is_np > 0 && wave < 3) lat_stage<I0, I1, NPW>(is_src, is_dst, src_off, wave, is_np);                  \
     } while (0)
 #define ISSUE_END()                                                                                               \
     do {                                                                                                          \
@@ -302,17 +351,17 @@ __global__ __launch_bounds__(256, 1) void latent_attn_kernel(LatentParams p) {
             if (wave < 3) issued += lat_pieces_of(is_np, wave);                                                   \
             if (islot == 0) mk0 = issued; else if (islot == 1) mk1 = issued; else mk2 = issued;                   \
             islot = islot + 1 == LAT_NST ? 0 : islot + 1;                                                         \
-            if (++it == cnt) { ir += nblk; it = 0; }                                                              \
+            if (++it == cnt) ISSUE_ADVANCE_ROW();                                                                 \
         }                                                                                                         \
     } while (0)
     // pieces of a sequence's last tile that hold valid keys (rows are 96 chunks, pieces 64 chunks)
-    const int np_last = (96 * (L - (cnt - 1) * LAT_TK) + 63) >> 6;
+    const int np_last = (96 * (L - (cnt - 1) * TK) + 63) >> 6;
     // The key rows such a trimmed request leaves alone keep whatever the slot held before: older X rows
     // (finite; their probabilities are exactly 0) - or, the first time round, whatever the previous kernel
     // left in LDS, possibly NaN patterns, and 0 x NaN would poison P.X.  So the ring is cleared once.
-    if (np_last < 48) {
+    if (np_last < NP) {
 #pragma unroll 4
-        for (int i = tid; i < LAT_NST * LAT_TILE_BYTES / 16; i += 256)
+        for (int i = tid; i < LAT_NST * TILE_BYTES / 16; i += 256)
             *reinterpret_cast<uint4*>(smem + (size_t)i * 16) = make_uint4(0, 0, 0, 0);
         __syncthreads();
     }
@@ -343,26 +392,27 @@ __global__ __launch_bounds__(256, 1) void latent_attn_kernel(LatentParams p) {
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             ISSUE_BEGIN();                        // refills the slot every wave has finished reading, in three parts
-            ISSUE_PART(0, 6);
-            const char* xt = smem + slot * LAT_TILE_BYTES;
+            ISSUE_PART(0, C::I1);
+            const char* xt = smem + slot * TILE_BYTES;
             slot = slot + 1 == LAT_NST ? 0 : slot + 1;
             STAMP(0)   // wait + barrier + DMA issue
 #ifndef MOCR_LAT_NOCOMPUTE   // timing experiment only: DMA ring without any consumer work
 
-            // ---- partial scores over this wave's 192 dims: S[head][key], two 16-key sub-tiles.  All twelve
+            // ---- partial scores over this wave's 192 dims: S[head][key], J 16-key sub-tiles.  All the
             // operand reads are issued before the first MFMA (left to itself hipcc serialises
             // read -> wait -> MFMA twelve times through one register quad)
             const unsigned xt_a = smem_base + (unsigned)(xt - smem);
-            f32x4 sacc[2];
+            f32x4 sacc[J];
             {
-                unsigned sa[12];
-                uint4 xs[12];
+                unsigned sa[6 * J];
+                uint4 xs[6 * J];
 #pragma unroll
-                for (int k = 0; k < 12; ++k) sa[k] = xt_a + s_off[k];
-                lds_read12_b128(xs, sa);
+                for (int k = 0; k < 6 * J; ++k) sa[k] = xt_a + s_off[k];
+                if constexpr (J == 2) lds_read12_b128(xs, sa);
+                else lds_read6_b128(xs, sa);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < J; ++j) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) sacc[j][r] = 0.f;
 #pragma unroll
@@ -376,46 +426,56 @@ __global__ __launch_bounds__(256, 1) void latent_attn_kernel(LatentParams p) {
             STAMP(1)   // S-phase reads + MFMAs
             // C/D map of the 16x16 MFMA: col = lane&15 (key), row = 4*(lane>>4) + reg (head)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < J; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) sS[(wave * 16 + 4 * g + r) * 32 + 16 * j + l15] = sacc[j][r];
+                for (int r = 0; r < 4; ++r) sS[(wave * 16 + 4 * g + r) * TK + 16 * j + l15] = sacc[j][r];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            ISSUE_PART(6, 11);
+            ISSUE_PART(C::I1, C::I2);
             // ---- online softmax, split over the waves: wave w owns accumulator register r = w, i.e. heads
-            // {4g + w}; a head's 32 keys sit on the 16 lanes of its group x 2 sub-tiles
-            float v0, v1;
+            // {4g + w}; a head's TK keys sit on the 16 lanes of its group x J sub-tiles
+            float v[J];
             {
-                const int o = (4 * g + wave) * 32 + l15;
-                v0 = (sS[o] + sS[512 + o]) + (sS[1024 + o] + sS[1536 + o]);
-                v1 = (sS[o + 16] + sS[512 + o + 16]) + (sS[1024 + o + 16] + sS[1536 + o + 16]);
+                const int o = (4 * g + wave) * TK + l15;
+#pragma unroll
+                for (int j = 0; j < J; ++j)
+                    v[j] = (sS[o + 16 * j] + sS[16 * TK + o + 16 * j]) + (sS[32 * TK + o + 16 * j] + sS[48 * TK + o + 16 * j]);
             }
             STAMP(2)   // partial-score exchange through LDS (write, barrier, read)
-            if (t * LAT_TK + l15 >= L) v0 = -INFINITY;
-            if (t * LAT_TK + 16 + l15 >= L) v1 = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < J; ++j)
+                if (t * TK + 16 * j + l15 >= L) v[j] = -INFINITY;
             {
-                float mx = v0 > v1 ? v0 : v1;
+                float mx = v[0];
+                if constexpr (J == 2) mx = v[0] > v[1] ? v[0] : v[1];
                 mx = row16_max(mx);
                 const float mn = mx > m_run ? mx : m_run;          // finite: every tile has a valid key
                 const float al = __expf(m_run - mn);
-                const float p0 = __expf(v0 - mn), p1 = __expf(v1 - mn);
-                l_run = l_run * al + row16_sum(p0 + p1);
+                float pe[J], psum = 0.f;
+#pragma unroll
+                for (int j = 0; j < J; ++j) { pe[j] = __expf(v[j] - mn); psum += pe[j]; }
+                l_run = l_run * al + row16_sum(psum);
                 m_run = mn;
-                bf16_t* pw = sP + (4 * g + wave) * 32 + l15;        // shared P[head][key]
-                pw[0] = f2bf(p0);
-                pw[16] = f2bf(p1);
+                bf16_t* pw = sP + (4 * g + wave) * TK + l15;        // shared P[head][key]
+#pragma unroll
+                for (int j = 0; j < J; ++j) pw[16 * j] = f2bf(pe[j]);
                 if (l15 == 0) sAl[4 * g + wave] = al;               // shared alpha[head]
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            ISSUE_PART(11, 16);
+            ISSUE_PART(C::I2, NPW);
             ISSUE_END();
-            // alpha[4g..4g+3] and the A operand P[head = lane&15][key = 8*g + jj] through inline asm: a plain
+            // alpha[4g..4g+3] and the A operand P[head = lane&15][keys of this lane group] through inline asm: a plain
             // LDS load here gets a compiler s_waitcnt vmcnt(0) in front (DMA-alias conservatism)
             uint4 ap[2];
-            lds_read2_b128(ap, lds_addr(sAl) + 16 * g, lds_addr(sP) + (l15 * 32 + 8 * g) * 2);
+            if constexpr (TK == 32) lds_read2_b128(ap, lds_addr(sAl) + 16 * g, lds_addr(sP) + (l15 * 32 + 8 * g) * 2);
+            else {
+                uint2 p2;
+                lds_read_b128_b64(ap[0], p2, lds_addr(sAl) + 16 * g, lds_addr(sP) + (l15 * 16 + 4 * g) * 2);
+                ap[1] = make_uint4(p2.x, p2.y, 0u, 0u);
+            }
             __builtin_amdgcn_sched_barrier(0);
             // rescale the accumulators only when some head's running max moved (wave-uniform test)
             {
@@ -430,10 +490,10 @@ __global__ __launch_bounds__(256, 1) void latent_attn_kernel(LatentParams p) {
             }
             STAMP(3)   // softmax + rescale
             // ---- C[head][d] += P[head][key] X[key][d] over this wave's 192 columns
-            union { uint4 u; bf16x8 v; } pcv;
-            pcv.u = ap[1];
-            const bf16x8 pf = pcv.v;
-            {
+            if constexpr (TK == 32) {
+                union { uint4 u; bf16x8 v; } pcv;
+                pcv.u = ap[1];
+                const bf16x8 pf = pcv.v;
                 // B operand: X[key = 8*g + jj][d0 + (lane&15)], read transposed: lane 4q+p of a 16-lane group
                 // supplies the address of row q, columns 4p..4p+3 of a 4 x 16 block and receives column
                 // (lane&15) of the 4 rows.  Two read groups of six column tiles (12 block reads) each.
@@ -456,17 +516,35 @@ __global__ __launch_bounds__(256, 1) void latent_attn_kernel(LatentParams p) {
                         cacc[6 * grp + k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, cv.v, cacc[6 * grp + k], 0, 0, 0);
                     }
                 }
+            } else {
+                // K = 16: A = P[head = lane&15][key = 4g + jj], B = X[key = 4g + jj][d0 + (lane&15)] - one transposed
+                // block read per column tile, all twelve in flight at once
+                union { uint2 u; lat_s16x4 v; } pcv;
+                pcv.u = make_uint2(ap[1].x, ap[1].y);
+                const lat_s16x4 pf = pcv.v;
+                unsigned ad[12];
+                uint2 xr[12];
+#pragma unroll
+                for (int k = 0; k < 12; ++k) ad[k] = xt_a + tr_off[k];
+                tr_read12(xr, ad);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < 12; ++k) {
+                    union { uint2 u; lat_s16x4 v; } cv;
+                    cv.u = xr[k];
+                    cacc[k] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pf, cv.v, cacc[k], 0, 0, 0);
+                }
             }
             STAMP(4)   // P read + transposed reads + P.X MFMAs
 #else
             (void)xt;
-            ISSUE_PART(6, 11);      // the bare ring: the whole request, no consumer work
-            ISSUE_PART(11, 16);
+            ISSUE_PART(C::I1, C::I2);      // the bare ring: the whole request, no consumer work
+            ISSUE_PART(C::I2, NPW);
             ISSUE_END();
 #endif
         }
-        // ---- finish the row: normalise, stage through LDS (two halves of 8 heads x 768 bf16 = 12 KiB,
-        // the score/probability scratch), store with 3 + 3 full 16-byte accesses per thread
+        // ---- finish the row: normalise, stage through LDS (12 heads x 768 bf16 = 18 KiB in the ring slot the last tile
+        // freed), store with 18 full 16-byte accesses per lane of wave 3
 #ifndef MOCR_LAT_NOEPI       // timing experiment only
         if (l15 == 0) sAl[16 + 4 * g + wave] = l_run;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -483,7 +561,8 @@ __global__ __launch_bounds__(256, 1) void latent_attn_kernel(LatentParams p) {
         // The ring slot of the tile just consumed is free until the next tile's top-of-loop barrier (its refill
         // is requested after that barrier), so all 12 heads x 768 bf16 are staged there in ONE pass: head rows
         // LAT_OUT_HS bytes apart (1536 + 16: the three lane groups of a wave then write different banks).
-        char* const stg = smem + islot * LAT_TILE_BYTES;
+        static_assert(12 * LAT_OUT_HS <= TILE_BYTES, "the finished row is staged in one ring slot");
+        char* const stg = smem + islot * TILE_BYTES;
         if (g < 3) {                                // lane group 3 holds the padding heads 12..15
             char* const wb = stg + (4 * g) * LAT_OUT_HS + (192 * wave + l15) * 2;
 #pragma unroll
@@ -523,7 +602,7 @@ __global__ __launch_bounds__(256, 1) void latent_attn_kernel(LatentParams p) {
 #endif
         // ---- the next row's Qt: prove the prefetch landed, then (and only then) copy it.  With >= 3 tiles
         // the wait for tile 2 (requested after the prefetch) already proved it; shorter rows wait here
-        // (at most 2 tiles = 24 younger loads).
+        // (at most 2 tiles = 2 NPW younger loads).
         if (cnt < 3 && wave < 3) wait_vm_newer(issued - mkq);
 #pragma unroll
         for (int s = 0; s < 6; ++s) asm volatile("" : "+v"(qn[s]));     // no copy may move above the wait
@@ -541,5 +620,7 @@ __global__ __launch_bounds__(256, 1) void latent_attn_kernel(LatentParams p) {
 #undef ISSUE_PART
 #undef ISSUE_END
 #undef ISSUE_NEXT
+#undef ISSUE_ADVANCE_ROW
 #undef Q_PTR
+#undef X_ROW
 }

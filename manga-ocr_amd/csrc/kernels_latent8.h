@@ -40,6 +40,7 @@ struct Latent8Params {
     const uint8_t* x8;          // keys: e4m3 rows of 768 B
     bf16_t* out;                // [rows][16][768] bf16  sum_key p * x[key]
     long long x_batch_stride;   // bytes between two sequences' first key
+    const int* rowmap;          // null: sequence r reads slot r of x8; else (compacted batches) slot rowmap[r]
     const int* step;            // self: context length = step[0] + 1; null: fixed_len
     int fixed_len;
     int heads;
@@ -93,6 +94,8 @@ __global__ __launch_bounds__(256, 1) void latent_attn_fp8_kernel(Latent8Params p
     const uint8_t* const P_x = p.x8;
     bf16_t* const P_out = p.out;
     const long long P_xstride = p.x_batch_stride;
+    const int* const P_rowmap = p.rowmap;
+#define X8_SLOT(row) ((size_t)(P_rowmap ? P_rowmap[row] : (row)))      // wave-uniform: a scalar load, no VMEM
     const int P_rows = p.rows, P_heads = p.heads;
     const float P_sx = p.sx;
     float* sS = reinterpret_cast<float*>(smem + LAT8_NST * LAT8_TILE_BYTES);       // [4][16][64] partial scores (16 KiB)
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(256, 1) void latent_attn_fp8_kernel(Latent8Params p
         if (ir < P_rows) {                                                                                        \
             const int np_ = it == cnt - 1 ? np_last : LAT8_PIECES;                                                \
             if (wave < 3) {                                                                                       \
-                lat8_stage(reinterpret_cast<const char*>(P_x) + (size_t)ir * P_xstride + (size_t)it * LAT8_TILE_BYTES, \
+                lat8_stage(reinterpret_cast<const char*>(P_x) + X8_SLOT(ir) * P_xstride + (size_t)it * LAT8_TILE_BYTES, \
                            smem + islot * LAT8_TILE_BYTES, src_off, wave, np_);                                   \
                 issued += lat_pieces_of(np_, wave);                                                               \
             }                                                                                                     \
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(256, 1) void latent_attn_fp8_kernel(Latent8Params p
         is_np = 0;                                                                                                \
         if (ir < P_rows) {                                                                                        \
             is_np = it == cnt - 1 ? np_last : LAT8_PIECES;                                                        \
-            is_src = reinterpret_cast<const char*>(P_x) + (size_t)ir * P_xstride + (size_t)it * LAT8_TILE_BYTES;   \
+            is_src = reinterpret_cast<const char*>(P_x) + X8_SLOT(ir) * P_xstride + (size_t)it * LAT8_TILE_BYTES;   \
             is_dst = smem + islot * LAT8_TILE_BYTES;                                                              \
         }                                                                                                         \
     } while (0)
@@ -443,6 +446,7 @@ __global__ __launch_bounds__(256, 1) void latent_attn_fp8_kernel(Latent8Params p
 #undef ISSUE_PART8
 #undef ISSUE_END8
 #undef Q_PTR
+#undef X8_SLOT
 }
 
 // bf16 rows -> e4m3 rows with one static scale (x8 = e4m3(x * inv_sx)): the encoder output of a batch, once per batch.

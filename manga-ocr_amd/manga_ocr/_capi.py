@@ -57,6 +57,7 @@ SYMBOLS = {
     "mocr_recognize_images": (C.c_int, [_P, C.POINTER(MocrImage), C.c_int32, _P, _P]),
     "mocr_recognize_regions": (C.c_int, [_P, C.POINTER(MocrImage), C.c_int32, C.POINTER(MocrRegion), C.c_int32, _P, _P]),
     "mocr_graph_count": (C.c_int, [_P]),
+    "mocr_compaction_count": (C.c_int64, [_P]),
     "mocr_device_memory": (C.c_int, [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "mocr_preprocess": (C.c_int, [_P, C.POINTER(MocrImage), C.c_int32, _P]),
     "mocr_recognize_device": (C.c_int, [_P, _P, C.c_int32, _P, _P]),

@@ -168,6 +168,10 @@ class Engine:
     def graph_count(self) -> int:
         return int(self.lib.mocr_graph_count(self._h))
 
+    def compaction_count(self) -> int:
+        """Row compactions performed so far: unfinished rows moved to the first decode slots between chunks of steps."""
+        return int(self.lib.mocr_compaction_count(self._h))
+
     def preprocess(self, images, bgr: bool = False, rotate=None) -> np.ndarray:
         """Test hook: the uint8 [n,224,224] planes the encoder sees for these crops."""
         descs, keep = self._image_descs(images, bgr, rotate)

@@ -366,14 +366,17 @@ def test_encoder_attention(dtype, impl, n):
     assert err <= tol
 
 
-@pytest.mark.parametrize("L,n", [(1, 5), (5, 5), (32, 5), (33, 5), (64, 5), (197, 5), (300, 5),
-                                 (20, 300), (40, 300), (70, 700), (197, 520)])
-def test_latent_attention(L, n):
+@pytest.mark.parametrize("tile", [16, 32])
+@pytest.mark.parametrize("L,n", [(1, 5), (5, 5), (16, 5), (17, 5), (32, 5), (33, 5), (48, 5), (64, 5), (197, 5), (300, 5),
+                                 (20, 300), (40, 300), (70, 700), (197, 520), (20, 1100), (40, 1300)])
+def test_latent_attention(L, n, tile):
     """softmax(Qt X^T) X per head with the heads on the MFMA rows; keys streamed through the LDS ring
-    in tiles of 32 (L = 1 .. 300 covers 1 to 10 tiles, partial last tiles and the ring's drain)."""
-    eng = engine("bf16")
+    in tiles of 16 (the default: two persistent blocks per CU) or 32 keys (MOCR_FLAG_LATENT_TILE32: r03's kernel shape);
+    L = 1 .. 300 covers 1 to 19 tiles, partial last tiles and the ring's drain; n > 512: persistent blocks take several
+    sequences each (1, 2 and 3+ tile rows)."""
+    eng = engine("bf16", flags=1024 if tile == 32 else 0)
     rs = np.random.RandomState(L)
-    H, D = 12, 768      # n > 256: persistent blocks take several sequences each (1, 2 and 3+ tile rows)
+    H, D = 12, 768
     stride = (L + 7) * D                                      # sequences are not tile-aligned in memory
     qt = np.zeros((n, 16, D), np.float32)
     qt[:, :H] = bf16_round((rs.standard_normal((n, H, D)) * 0.08).astype(np.float32))
@@ -390,7 +393,7 @@ def test_latent_attention(L, n):
     eng.op_latent_attention(dq, dx, do, n, L, stride)
     got = do[:, :H].float().cpu().numpy().astype(np.float64)
     err = np.abs(got - ref).max()
-    report(f"latent attention L={L}: max abs err {err:.3e} (|ref| max {np.abs(ref).max():.2f})")
+    report(f"latent attention tile {tile} L={L} n={n}: max abs err {err:.3e} (|ref| max {np.abs(ref).max():.2f})")
     assert np.isfinite(got).all() and err <= 3e-2
 
 

@@ -6,7 +6,8 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "manga-ocr_amd")]
 import torch
 from manga_ocr.engine import Engine
 from manga_ocr.weights import DEFAULT_SPEC, synthetic_weights
-eng = Engine(synthetic_weights(0), DEFAULT_SPEC, dtype="bf16", max_batch=8)
+FLAGS = int(os.environ.get("FLAGS", "0"))      # engine flags, e.g. 1024 = MOCR_FLAG_LATENT_TILE32
+eng = Engine(synthetic_weights(0), DEFAULT_SPEC, dtype="bf16", max_batch=8, flags=FLAGS)
 Ls = [int(v) for v in os.environ.get("LS", "32,96,197,300").split(",")]
 for n in [int(v) for v in os.environ.get("N", "2048").split(",")]:
   for L in Ls:
@@ -22,4 +23,4 @@ for n in [int(v) for v in os.environ.get("N", "2048").split(",")]:
       st = eng.profile_get()[0]; eng.profile_enable(False)
       us = st["total_ms"] / st["launches"] * 1e3
       tiles = (L + 31) // 32
-      print(f"n={n} L={L:4d}: {us:8.1f} us  {n * L * 1536 / us / 1e3:7.1f} GB/s   {us * 256 / n / tiles:6.2f} us per tile-block", flush=True)
+      print(f"flags={FLAGS} n={n} L={L:4d}: {us:8.1f} us  {n * L * 1536 / us / 1e3:7.1f} GB/s   {us * 256 / n / tiles:6.2f} us per tile-block", flush=True)
