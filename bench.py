@@ -36,7 +36,7 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_BF16_PEAK_TF = 2500.0   # dense bf16 MFMA
 MFMA_F32_PEAK_TF = 157.3     # f32-input MFMA
-ROUND = "r03"
+ROUND = "r04"
 
 ENC_FLOPS_PER_CROP = 35_126_120_448
 
@@ -110,6 +110,30 @@ def cpu_baseline(args, weights):
             "regimes": regimes}
 
 
+class _FakeEngine:
+    """CPU stand-in for the HIP engine, ONLY for the gloo rehearsal of the N > 1 path (MOCR_BENCH_FAKE_ENGINE=1,
+    tests/test_bench_gloo.py): the same submit / synchronize surface, ids[b] = (start, byte-sum of crop b mod 6000, eos).
+    Never measured, never shipped: the product path fails loudly without the HIP library."""
+
+    def __init__(self, max_len):
+        self.max_len = max_len
+
+    def recognize_device(self, d_gray, n, out_ids, out_len):
+        import torch
+        key = d_gray[:n].reshape(n, -1).to(torch.int64).sum(1) % 6000
+        out_ids[:n].zero_()
+        out_ids[:n, 0] = 2
+        out_ids[:n, 1] = key.to(torch.int32)
+        out_ids[:n, 2] = 3
+        out_len[:n] = 3
+
+    def synchronize(self):
+        pass
+
+    def close(self):
+        pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -129,7 +153,8 @@ def main():
     ap.add_argument("--no-config4", action="store_true", help="skip the variable-resolution + fp8-attention record")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-parity-leg", action="store_true", help="skip the fp32 parity-mode / bf16 id-match record (tests/golden crops)")
-    ap.add_argument("--rows-per-rank-probe", type=int, default=0,
+    ap.add_argument("--no-mixed", action="store_true", help="skip the mixed-lengths record (EOS-biased weights, row compaction on / off)")
+    ap.add_argument("--rows-per-rank-probe", type=int, default=1250,
                     help="time ONE batch of this many rows (10000 / 8 = 1250: what a rank of the 8-GPU strong-scaling run decodes) and "
                          "report the strong-scaling bound it implies")
     ap.add_argument("--only-timed", action="store_true",
@@ -154,7 +179,15 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 as: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         args.gpus = world
-    torch.cuda.set_device(local)
+    # MOCR_BENCH_FAKE_ENGINE=1: the rank / shard / gather / max-over-ranks logic of this file on CPU tensors over gloo, with a
+    # stand-in engine - the world-2 rehearsal tests/test_bench_gloo.py runs where there is no GPU.  Timed region only.
+    fake = bool(os.environ.get("MOCR_BENCH_FAKE_ENGINE"))
+    dev = "cpu" if fake else "cuda"
+    if fake:
+        args.only_timed = True
+        torch.cuda.synchronize = lambda *a, **k: None
+    else:
+        torch.cuda.set_device(local)
     dist = None
     # MOCR_BENCH_FORCE_DIST=1: take the collective path (process group, barrier, all-gather, max over ranks) even with
     # one rank - a rehearsal of the N > 1 code on a one-GPU box
@@ -162,13 +195,16 @@ def main():
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if fake:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     spec = dataclasses.replace(DEFAULT_SPEC, max_len=args.max_len)
-    weights = synthetic_weights(0)
+    weights = None if fake else synthetic_weights(0)
     args.max_batch = max(args.max_batch, args.batch)
-    eng = Engine(weights, spec, dtype=args.dtype, device=local, max_batch=args.max_batch, lanes=args.lanes,
-                 flags=(128 if args.fp8_attention else 0) | args.engine_flags)
+    eng = _FakeEngine(args.max_len) if fake else Engine(weights, spec, dtype=args.dtype, device=local, max_batch=args.max_batch, lanes=args.lanes,
+                                                         flags=(128 if args.fp8_attention else 0) | args.engine_flags)
     dtype_label = args.dtype + ("+fp8attn" if args.fp8_attention else "")
     B, L = args.batch, args.max_len
     strong = args.queue > 0
@@ -180,15 +216,15 @@ def main():
         n_local = n_max = steps_local = 0
     # this rank's crops: global crop ids [rank*B, (rank+1)*B) of every step (weak), or its shard of the queue (strong)
     gray = np.random.RandomState(1234 + rank).randint(0, 256, size=(B, 224, 224), dtype=np.uint8)
-    d_gray = torch.from_numpy(gray).cuda()
+    d_gray = torch.from_numpy(gray).to(dev)
     K = max(args.steps, args.warmup, steps_local, 1)
-    d_ids = torch.zeros((K, B, L), dtype=torch.int32, device="cuda")      # one output block per step
-    d_len = torch.zeros((K, B), dtype=torch.int32, device="cuda")
+    d_ids = torch.zeros((K, B, L), dtype=torch.int32, device=dev)      # one output block per step
+    d_len = torch.zeros((K, B), dtype=torch.int32, device=dev)
     if strong:
-        d_rows = torch.zeros((n_max, L + 1), dtype=torch.int32, device="cuda")
-        d_all = torch.zeros((world * n_max, L + 1), dtype=torch.int32, device="cuda") if use_dist else None
+        d_rows = torch.zeros((n_max, L + 1), dtype=torch.int32, device=dev)
+        d_all = torch.zeros((world * n_max, L + 1), dtype=torch.int32, device=dev) if use_dist else None
     else:
-        d_all = torch.zeros((world * K, B, L), dtype=torch.int32, device="cuda") if use_dist else None
+        d_all = torch.zeros((world * K, B, L), dtype=torch.int32, device=dev) if use_dist else None
     torch.cuda.synchronize()
 
     def run(nsteps):
@@ -226,7 +262,7 @@ def main():
         fence()
         dt = time.perf_counter() - t0
         if use_dist:
-            tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
         return dt
@@ -312,7 +348,10 @@ def main():
         except (OSError, ValueError, KeyError):
             pass
         roof = {"kernel": k0["kernel"], "bound": k0["bound"], "achieved": k0["achieved"], "peak": k0["peak"],
-                "unit": k0["unit"], "frac": k0["frac"], "traffic": traffic, "avg_us": k0["avg_us"],
+                "unit": k0["unit"], "frac": k0["frac"], "traffic": traffic,
+                "traffic_source": (f"profiles/{ROUND}_pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
+                                   "committed with the round - NOT measured inside this run") if traffic is not None else None,
+                "avg_us": k0["avg_us"],
                 "algorithmic_per_launch": k0["algorithmic_per_launch"], "rows": rows_prof, "share_of_step": k0["share"]}
         # ---- encoder only at this batch: the north star's ">= 50 % of the bf16 MFMA peak at batch 256" target
         eng.profile_reset()
@@ -399,12 +438,88 @@ def main():
         dt_b, rows_b, toks_b, worst_b = run_on(eng)
         eng32 = Engine(weights, spec, dtype="fp32", device=local, max_batch=256, lanes=1)
         dt_f, rows_f, toks_f, worst_f = run_on(eng32)
+        # where the parity mode's time goes: the encoder alone (HIP events over its launches), the rest is the 299 decode steps
+        eng32.profile_enable(True)
+        eng32.profile_reset()
+        eng32.encode(dgc, 256)
+        enc32_ms = sum(s_["total_ms"] for s_ in eng32.profile_get())
+        eng32.profile_enable(False)
         eng32.close()
         parity = {"crops": "the 256 golden crops of tests/golden/bf16_parity.npz (reference ids: transformers greedy generate, fp32)",
-                  "fp32_parity_mode": {"crops_per_s": 256 / dt_f, "ms_per_256_crop_batch": dt_f * 1e3, "ids_identical": toks_f,
-                                       "rows_identical_frac": rows_f, "max_reference_margin_at_a_divergence": worst_f},
+                  "parity_mode_fp32": {"crops_per_s": 256 / dt_f, "ms_per_256_crop_batch": dt_f * 1e3, "ids_identical": toks_f,
+                                       "rows_identical_frac": rows_f, "max_reference_margin_at_a_divergence": worst_f,
+                                       "encoder_ms": enc32_ms, "decode_and_rest_ms": dt_f * 1e3 - enc32_ms,
+                                       "encoder_tflops_f32_mfma": ENC_FLOPS_PER_CROP * 256 / (enc32_ms * 1e-3) / 1e12,
+                                       "note": "f32-input MFMA (157 TF peak) for every GEMM, fp32 K/V caches (1.2 MB per crop and layer of "
+                                               "cross keys/values per step): what bit-identical ids cost; DESIGN.md 2 has why split-bf16 "
+                                               "GEMMs would not keep ids_identical at 1.0"},
                   "bf16_rows_identical_frac": rows_b, "bf16_tokens_identical_frac": toks_b,
                   "bf16_max_reference_margin_at_a_divergence": worst_b, "bf16_ms_per_256_crop_batch": dt_b * 1e3}
+
+    # ---- rows of DIFFERENT lengths (r04).  In the reference every crop is its own generate() call and stops at its own EOS
+    # (TF/generation/utils.py:2929-2937 via src/ui/main_window.py:9801); the headline's synthetic weights never emit EOS.  This leg
+    # uses the EOS-biased synthetic weights of tests/golden/early_eos_seed1.npz (seed 1, eos_bias 1.1): rows end after ~17 .. 300
+    # tokens.  Same queue shape as the headline (steps of B crops merged by the engine), with the engine's row compaction and -
+    # second engine - without it (MOCR_FLAG_NO_COMPACTION); `mean_length_time_s` is the headline engine decoding the same
+    # number of crops with EVERY row at the mixed queue's mean length (what an ideal scheduler's decode work amounts to).
+    mixed = None
+    if extras and not strong and not light and not args.no_mixed and args.dtype == "bf16" and L == 300:
+        wm = synthetic_weights(1, eos_bias=1.1)
+        mb = min(args.max_batch, 2560)
+        nq = min(args.steps, 20) * B
+        gm = np.random.RandomState(4322).randint(0, 256, size=(nq, 224, 224), dtype=np.uint8)
+        dgm = torch.from_numpy(gm).cuda()
+        oi = torch.zeros((nq, L), dtype=torch.int32, device="cuda")
+        ol = torch.zeros((nq,), dtype=torch.int32, device="cuda")
+
+        def run_mixed(e):
+            best, slots = 1e9, 0
+            for _ in range(2):                       # the first pass captures the graphs of every compacted row count
+                s0 = e.decode_slot_steps()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for i in range(0, nq, B):
+                    e.recognize_device(dgm[i:i + B], min(B, nq - i), oi[i:i + B], ol[i:i + B])
+                e.synchronize()
+                torch.cuda.synchronize()
+                best = min(best, time.perf_counter() - t1)
+                slots = e.decode_slot_steps() - s0
+            return best, slots, ol.cpu().numpy().copy(), oi.cpu().numpy().copy()
+
+        res = {}
+        for name, fl in (("compacted", 0), ("uncompacted", 2048)):
+            em = Engine(wm, spec, dtype=args.dtype, device=local, max_batch=mb, lanes=args.lanes, flags=fl | args.engine_flags)
+            dtm, slots, lens_m, ids_m = run_mixed(em)
+            ncomp = em.compaction_count()
+            em.close()
+            res[name] = (dtm, slots, lens_m, ids_m, ncomp)
+        lens_m = res["compacted"][2]
+        tokens = int((lens_m - 1).sum())
+        mean_len = float(lens_m.mean())
+        # the headline engine, every row exactly mean_len tokens long (EOS never fires there)
+        ml = int(round(mean_len))
+        eng.set_generate_max_length(ml)
+        tmean = 1e9
+        for _ in range(2):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(0, nq, B):
+                eng.recognize_device(d_gray, B, d_ids[(i // B) % K], d_len[(i // B) % K])
+            eng.synchronize()
+            torch.cuda.synchronize()
+            tmean = min(tmean, time.perf_counter() - t1)
+        eng.set_generate_max_length(L)
+        mixed = {"workload": f"{nq} synthetic crops in steps of {B}, EOS-biased weights (seed 1, eos_bias 1.1), engine max_batch {mb}, {args.lanes} lanes, max_len {L}",
+                 "lengths": {"min": int(lens_m.min()), "mean": mean_len, "max": int(lens_m.max()),
+                             "deciles": [int(v) for v in np.percentile(lens_m, [10, 20, 30, 40, 50, 60, 70, 80, 90])]},
+                 "crops_per_s": nq / res["compacted"][0], "seconds": res["compacted"][0], "compactions": res["compacted"][4],
+                 "useful_token_fraction": tokens / max(res["compacted"][1], 1),
+                 "uncompacted": {"crops_per_s": nq / res["uncompacted"][0], "seconds": res["uncompacted"][0],
+                                 "useful_token_fraction": tokens / max(res["uncompacted"][1], 1)},
+                 "ids_identical_to_uncompacted": bool((res["compacted"][3] == res["uncompacted"][3]).all()),
+                 "mean_length_time_s": tmean, "mean_length_tokens": ml,
+                 "time_over_mean_length_time": res["compacted"][0] / tmean}
+        del dgm, oi, ol
 
     # ---- strong-scaling probe: ONE batch of the rows a rank of the 8-GPU queue run gets, alone on this GPU
     probe = None
@@ -422,9 +537,12 @@ def main():
             torch.cuda.synchronize()
             dtp = time.perf_counter() - t1
         probe = {"rows": rows, "ms": dtp * 1e3, "crops_per_s_one_gpu": rows / dtp,
-                 "implied_8gpu_queue_crops_per_s": 8 * rows / dtp,
-                 "implied_speedup_over_this_run": (8 * rows / dtp) / value,
-                 "note": "8 ranks x this batch, before the one all-gather; `this run` = the value of this JSON line"}
+                 "extrapolated_8gpu_queue_crops_per_s_upper_bound": 8 * rows / dtp,
+                 "extrapolated_speedup_over_this_run_upper_bound": (8 * rows / dtp) / value,
+                 "note": "an EXTRAPOLATION, not a measurement: 8 x the rate of one rank's share (10000 / 8 rows) decoded alone on this one GPU - "
+                         "an upper bound on what 8 ranks reach before start-up skew, the one all-gather and, in the product "
+                         "(MangaOcr(devices=...)), the pull-based dealing of chunks; no 8-GPU run backs it until the driver's SCALE record does; "
+                         "`this run` = the value of this JSON line"}
 
     cpu = None
     if extras and world == 1 and not args.no_cpu_baseline:
@@ -453,9 +571,13 @@ def main():
             # `value` is the throughput of the whole queue of steps: the engine merges the submitted steps into internal
             # batches of up to engine_max_batch rows (split over its lanes).  One batch submitted ALONE takes (ms):
             "isolated_step_ms": isolated, "regime_T32": t32, "encoder_only": enc_only, "config4_variable_res_fp8": cfg4,
-            "parity": parity, "strong_scaling_probe": probe,
+            "parity": parity, "mixed_lengths": mixed, "strong_scaling_probe": probe,
             "roofline": roof, "cpu_baseline": cpu, "kernels": kernels[:24],
         }
+        if fake:      # the rehearsal's evidence that every rank's rows arrived, in rank order
+            out["data"] = "synthetic (FAKE ENGINE: a CPU rehearsal of the collective path, not a measurement)"
+            out["gathered_checksum"] = int(d_all.to(torch.int64).sum().item()) if d_all is not None else None
+            out["gathered_shape"] = list(d_all.shape) if d_all is not None else None
         line = json.dumps(out)
     else:
         line = None

@@ -60,10 +60,13 @@ enum {
                                            * step latency there: 50 instead of 80 ms for 64 crops) */
     MOCR_FLAG_NO_SMALL_BATCH_PATH = 1 << 8, /* bf16: batches of <= 32 rows through the generic split-K projections + add/LayerNorm
                                            * launches (28 per decode step) instead of the one-launch-per-projection path (19) */
-    MOCR_FLAG_LATENT_TILE32 = 1 << 10,    /* bf16 latent attention on r03's kernel shape (32-key tiles, one persistent block per CU)
-                                           * instead of 16-key tiles on two blocks per CU: the A/B partner */
+    MOCR_FLAG_LATENT_TILE32 = 1 << 10,    /* bf16 latent attention on r03's kernel shape (32-key tiles, one persistent block per CU, three
+                                           * barriers per tile) instead of 16-key tiles on two blocks per CU with the score tile
+                                           * transposed (two barriers per tile): the A/B partner */
     MOCR_FLAG_NO_COMPACTION = 1 << 11,    /* keep every row of a batch in the decode steps until the whole batch has finished (r01-r03
                                            * behaviour) instead of compacting the unfinished rows between chunks of steps */
+    MOCR_FLAG_FORCE_LN_FOLD = 1 << 13,    /* bf16: fold the encoder's LayerNorms even where this checkpoint's residual stream failed the
+                                           * commit-time check (mocr_ln_fold_state): A/B and tests only */
     MOCR_FLAG_NO_LN_FOLD = 1 << 9         /* bf16: the encoder's LayerNorms as launches of their own even where the layer GEMMs run on
                                            * the persistent kernel (default there: folded into the GEMMs on both sides of them) */
 };
@@ -229,6 +232,17 @@ int mocr_graph_count(mocr_engine* e);
  * one-generate()-per-crop loop, where a short text stops at its own EOS (TF/generation/utils.py:2929-2937 via
  * src/ui/main_window.py:9801).  Test hook / statistic; MOCR_FLAG_NO_COMPACTION keeps it at 0. */
 int64_t mocr_compaction_count(mocr_engine* e);
+/* Decode slots x greedy steps enqueued since mocr_create (statistic): the row-steps the decode launches were sized for.  The
+ * tokens a caller got (sum of out_len - 1) over this number is the useful fraction of the decode work - 1.0 for the
+ * reference's one-generate()-per-crop loop; mean / max length for a lock-step batch without compaction. */
+int64_t mocr_decode_slot_steps(mocr_engine* e);
+/* LayerNorm folding of the bf16 encoder (r03: the 24 LayerNorms between the persistent layer GEMMs applied in those GEMMs'
+ * epilogues, the GEMMs reading bf16(x) instead of bf16(LN(x)); TF/models/vit/modeling_vit.py:266-286 is the unfolded form).
+ * mocr_commit_weights measures, on eight probe crops, how much more input-rounding noise that costs on THIS checkpoint's
+ * residual stream: *noise_ratio = sqrt(sum (x g rstd)^2 / sum LN(x)^2), worst LayerNorm (~1 on a near-normalised stream,
+ * ~|mean| / spread on one with a DC offset).  Returns 1 when fat batches fold (ratio <= 1.5, or MOCR_FLAG_FORCE_LN_FOLD), 0
+ * when the LayerNorms stay launches (ratio above, fp32 engine, MOCR_FLAG_NO_LN_FOLD). */
+int mocr_ln_fold_state(mocr_engine* e, float* noise_ratio);
 /* Free / total bytes of HBM on a device (the Python constructor sizes its default max_batch from it). */
 int mocr_device_memory(int32_t device, int64_t* free_bytes, int64_t* total_bytes);
 

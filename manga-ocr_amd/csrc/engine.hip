@@ -39,6 +39,7 @@
 #endif
 #include "kernels_latent.h"
 #include "kernels_latent8.h"
+#include "kernels_latent_t.h"
 #include "kernels_smallm.h"
 #include "preprocess.h"
 #include "prep_pipeline.h"
@@ -170,8 +171,17 @@ struct mocr_engine : LaneCtx {
     bool fp8attn = false;           // latent attention on e4m3 key/value rows + fp8 MFMA (MOCR_FLAG_FP8_ATTENTION, opt-in)
     bool latent = false;            // bf16 engines: latent (absorbed) decode attention ...
     int classic_rows = 0;           // ... for batches of more than this many rows; smaller ones use the classic kernels
+    // LayerNorm folding (bf16, persistent encoder GEMMs) is gated by a measurement on THIS checkpoint (calibrate_ln_fold):
+    // the fold feeds bf16(x) - the raw residual stream - into the matrix cores where the launches feed bf16(LN(x)); per row
+    // the input-rounding noise of the two forms is in the ratio sqrt(sum (x g rstd)^2 / sum (LN(x))^2), ~1 on a
+    // near-normalised stream and |mean| / spread on a stream with a DC offset.
+    struct FoldCalib { std::vector<std::vector<float>> g, b; size_t idx = 0; double worst = 0.0; std::vector<float> hx; };
+    FoldCalib* calib = nullptr;     // non-null only inside calibrate_ln_fold
+    bool fold_ok = true;            // the measured ratio allows the fold (<= FOLD_RATIO_MAX on every LayerNorm input)
+    float fold_ratio = 0.f;         // the worst ratio measured (0: not measured)
+    long long n_slot_steps = 0;     // decode slots x steps enqueued so far (mocr_decode_slot_steps): what the steps cost, in rows
     long long n_compactions = 0;    // batches whose rows were compacted, counted per compaction (mocr_compaction_count)
-    int lat_tk = 16;                // keys per tile of the bf16 latent attention: 16 (two blocks per CU) or 32 (MOCR_FLAG_LATENT_TILE32)
+    int lat_tk = 17;                // bf16 latent attention kernel: 17 = latent_attnT_kernel (default); 16 / 32 = latent_attn_kernel on 16- / 32-key tiles
     int Bc = 0;                     // rows the classic K/V buffers are sized for
     // Kernel regime of the batch being decoded: the row count the batch STARTED with (0: the launch's own row count).
     // Every choice a decode step makes by row count - attention path, GEMM tile, split-K slabs, fused query kernel,
@@ -659,6 +669,34 @@ void enc_attention(mocr_engine* e, const void* qkv, void* ctx, int n, int impl) 
     HIPCHECK(hipGetLastError());
 }
 
+// calibrate_ln_fold's observer: X [M, 768] is the input of the LayerNorm about to run.  Per row, the rounding noise the GEMM
+// behind it sees when it is fed bf16(x) (the fold) over the noise when it is fed bf16(LN(x)) (the launch):
+//     sqrt( sum_k (x_k g_k rstd)^2 / sum_k ((x_k - mean) rstd g_k + b_k)^2 ),    rms over the rows; the worst LayerNorm counts.
+static void calib_observe(mocr_engine* e, int M) {
+    auto& c = *e->calib;
+    if (c.idx >= c.g.size()) return;                 // (the encoder's final LayerNorm is never folded)
+    const int D = e->D;
+    c.hx.resize((size_t)M * D);
+    HIPCHECK(hipMemcpyAsync(c.hx.data(), e->X, (size_t)M * D * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIPCHECK(hipStreamSynchronize(e->stream));
+    const std::vector<float>&g = c.g[c.idx], &b = c.b[c.idx];
+    double num = 0.0, den = 0.0;
+    for (int m = 0; m < M; ++m) {
+        const float* x = c.hx.data() + (size_t)m * D;
+        double s = 0.0, q = 0.0;
+        for (int k = 0; k < D; ++k) s += x[k];
+        const double mean = s / D;
+        for (int k = 0; k < D; ++k) { const double d = x[k] - mean; q += d * d; }
+        const double rstd = 1.0 / std::sqrt(q / D + (double)e->cfg.ln_eps);
+        for (int k = 0; k < D; ++k) {
+            const double a = (double)x[k] * g[k] * rstd, y = ((double)x[k] - mean) * rstd * g[k] + b[k];
+            num += a * a; den += y * y;
+        }
+    }
+    c.worst = std::max(c.worst, std::sqrt(num / std::max(den, 1e-300)));
+    c.idx += 1;
+}
+
 template <typename T>
 void run_encoder(mocr_engine* e, const uint8_t* d_gray, int n) {
     const int D = e->D, F = e->F, S = e->S, M = n * S, P = e->cfg.patch_size, IMG = e->cfg.image_size;
@@ -727,7 +765,7 @@ void run_encoder(mocr_engine* e, const uint8_t* d_gray, int n) {
     const long long blocks64 = (long long)((M + 63) / 64) * (D / 64);
     int split_o = 1, split_2 = 1;
     static const int enc_split_blocks = env_int("MOCR_ENC_SPLITK_BLOCKS", 0);      // largest unsplit 64 x 64 grid that is split (0: one block per CU)
-    if (enc_split_env && !enc_tile_env && ETO == 64 && blocks64 <= (enc_split_blocks ? enc_split_blocks : e->num_cus)) {
+    if (enc_split_env && !enc_tile_env && !e->calib && ETO == 64 && blocks64 <= (enc_split_blocks ? enc_split_blocks : e->num_cus)) {
         split_o = 3; split_2 = 8;
         while (split_2 > 1 && (long long)M * D * split_2 > e->slab_cap) split_2 >>= 1;
         if ((long long)M * D * split_o > e->slab_cap) split_o = 1;
@@ -740,11 +778,12 @@ void run_encoder(mocr_engine* e, const uint8_t* d_gray, int n) {
     if constexpr (sizeof(T) == 2) {
         static const int fold_env = env_int("MOCR_ENC_LN_FOLD", 1);
         fold = fold_env && !(e->cfg.flags & MOCR_FLAG_NO_LN_FOLD) && ETQ == 4096 && ETO == 4096 && ET1 == 4096 && ET2 == 4096 &&
-               D == 768 && w.enc[0].wqkv_f;
+               D == 768 && w.enc[0].wqkv_f && !e->calib && (e->fold_ok || (e->cfg.flags & MOCR_FLAG_FORCE_LN_FOLD));
     }
     const float* pend_bias = nullptr;      // bias of a split GEMM whose slabs the next LayerNorm has to add to X
     int pend_slabs = 0;
     auto norm = [&](const float* g, const float* b, void* out) {
+        if (e->calib && !pend_slabs) calib_observe(e, M);
         if (!pend_slabs) { layernorm<T>(e, e->X, g, b, out, M); return; }
         ProfScope ps(e, "layernorm_slab", 0, (double)M * D * (4.0 * (pend_slabs + 2) + sizeof(T)));
         hipLaunchKernelGGL((layernorm_slab_kernel<T, 768>), dim3((M + 3) / 4), dim3(256), 0, e->stream, e->X, e->slabs, pend_slabs,
@@ -936,13 +975,19 @@ void dec_attn(mocr_engine* e, int layer, int nslab, int n, const float* bias, in
     HIPCHECK(hipGetLastError());
 }
 
-// The bf16 latent attention launch: 16-key tiles, two persistent blocks per CU (r04; kernels_latent.h) or - MOCR_FLAG_LATENT_TILE32,
-// the A/B partner - r03's 32-key tiles on one block per CU.
+// The bf16 latent attention launch (r04).  Default: latent_attnT_kernel - 16-key tiles on two persistent blocks per CU, the score
+// tile transposed so that the softmax's probabilities feed P.X from registers (two barriers per tile; kernels_latent_t.h).
+// MOCR_FLAG_LATENT_TILE32 = r03's kernel shape, the A/B partner: latent_attn_kernel on 32-key tiles, one block per CU (three
+// barriers per tile, kernels_latent.h).  Experiments build, MOCR_LAT_TK=16: that kernel on 16-key tiles, two blocks per CU
+// (the first half of r04; equal to the default within noise).
 void launch_latent(mocr_engine* e, bool self, const LatentParams& p) {
     static const int lat_blocks = env_int("MOCR_LAT_BLOCKS", 0);      // persistent blocks (experiments; 0: one or two per CU by tile)
-    const int per_cu = e->lat_tk == 16 ? 2 : 1;
+    const int per_cu = e->lat_tk == 32 ? 1 : 2;
     const int grid = std::min(p.rows, lat_blocks > 0 ? lat_blocks : per_cu * e->num_cus);
-    if (e->lat_tk == 16) {
+    if (e->lat_tk == 17) {
+        if (self) hipLaunchKernelGGL(latent_attnT_kernel<true>, dim3(grid), dim3(256), LAT3_LDS, e->stream, p);
+        else hipLaunchKernelGGL(latent_attnT_kernel<false>, dim3(grid), dim3(256), LAT3_LDS, e->stream, p);
+    } else if (e->lat_tk == 16) {
         if (self) hipLaunchKernelGGL((latent_attn_kernel<true, 16>), dim3(grid), dim3(256), LatCfg<16>::LDS, e->stream, p);
         else hipLaunchKernelGGL((latent_attn_kernel<false, 16>), dim3(grid), dim3(256), LatCfg<16>::LDS, e->stream, p);
     } else {
@@ -1285,6 +1330,8 @@ template <typename T> void init_kernel_attrs() {
     set_max_lds(latent_attn_kernel<false, 32>, LatCfg<32>::LDS);
     set_max_lds(latent_attn_kernel<true, 16>, LatCfg<16>::LDS);
     set_max_lds(latent_attn_kernel<false, 16>, LatCfg<16>::LDS);
+    set_max_lds(latent_attnT_kernel<true>, LAT3_LDS);
+    set_max_lds(latent_attnT_kernel<false>, LAT3_LDS);
     set_max_lds(latent_attn_fp8_kernel<true>, LAT8_LDS);
     set_max_lds(latent_attn_fp8_kernel<false>, LAT8_LDS);
 }
@@ -1464,6 +1511,7 @@ void advance(mocr_engine* e, Lane& L) {
         }
     }
     L.t += k;
+    e->n_slot_steps += (long long)L.np * k;
     if (early) {
         HIPCHECK(hipMemcpyAsync(e->h_pinned + slot, e->n_unf, sizeof(int), hipMemcpyDeviceToHost, e->stream));
         HIPCHECK(hipEventRecord(L.flag_ev[slot], e->stream));
@@ -1582,10 +1630,44 @@ static std::vector<float> concat(std::initializer_list<const std::vector<float>*
     return out;
 }
 
+// Is this checkpoint's residual stream one the LayerNorm fold may round to bf16?  Eight probe crops (six of seeded noise, one
+// white, one black) go through the encoder with the LayerNorms as launches; in front of each of the 24 foldable LayerNorms
+// the stream is copied out and the rounding-noise ratio of calib_observe is taken.  Synthetic N(0, 0.02^2) weights: ~1.0-1.1.
+// A stream with a DC offset of several sigma (trained ViTs): several - the fold would cost that factor in GEMM input noise,
+// and stays off.  Run once per engine, at commit (~30 ms); mocr_ln_fold_state reports the outcome.
+constexpr double FOLD_RATIO_MAX = 1.5;
+void calibrate_ln_fold(mocr_engine* e, mocr_engine::FoldCalib& cal) {
+    const int n = 8;
+    if (e->cfg.max_batch < 56 || e->D != 768 || e->lanes.empty()) return;      // batches this small never take the persistent GEMMs
+    const size_t plane = (size_t)e->cfg.image_size * e->cfg.image_size;
+    std::vector<uint8_t> probe(n * plane);
+    uint32_t lcg = 12345u;
+    for (size_t i = 0; i < 6 * plane; ++i) { lcg = lcg * 1664525u + 1013904223u; probe[i] = (uint8_t)(lcg >> 24); }
+    std::fill(probe.begin() + 6 * plane, probe.begin() + 7 * plane, (uint8_t)255);
+    std::fill(probe.begin() + 7 * plane, probe.end(), (uint8_t)0);
+    e->bind(0);
+    HIPCHECK(hipMemcpyAsync(e->d_in, probe.data(), probe.size(), hipMemcpyHostToDevice, e->stream));
+    cal.idx = 0; cal.worst = 0.0;
+    e->calib = &cal;
+    try {
+        run_encoder<bf16_t>(e, e->d_in, n);
+        HIPCHECK(hipStreamSynchronize(e->stream));
+    } catch (...) {
+        e->calib = nullptr;
+        e->unbind(0);
+        throw;
+    }
+    e->calib = nullptr;
+    e->unbind(0);
+    e->fold_ratio = (float)cal.worst;
+    e->fold_ok = cal.worst <= FOLD_RATIO_MAX;
+}
+
 void commit_weights(mocr_engine* e) {
     const auto& c = e->cfg;
     const int64_t D = c.hidden, F = c.ffn, V = c.vocab, P = c.patch_size, S = e->S;
     Uploader up{e};
+    mocr_engine::FoldCalib ln_gb;
     auto& w = e->w;
     // pixel LUT, exactly the HF image processor's arithmetic (float64 rescale, float32 normalise)
     {
@@ -1654,6 +1736,8 @@ void commit_weights(mocr_engine* e) {
                                         &up.get(p + "attention.v_proj.bias", {D})});
             fold(wqkv_h, bqkv_h, up.get(p + "layernorm_before.weight", {D}), up.get(p + "layernorm_before.bias", {D}), 3 * D,
                  L.wqkv_f, L.sqkv, L.bqkv_f);
+            ln_gb.g.push_back(up.get(p + "layernorm_before.weight", {D})); ln_gb.b.push_back(up.get(p + "layernorm_before.bias", {D}));
+            ln_gb.g.push_back(up.get(p + "layernorm_after.weight", {D})); ln_gb.b.push_back(up.get(p + "layernorm_after.bias", {D}));
             fold(up.get(p + "mlp.fc1.weight", {F, D}), up.get(p + "mlp.fc1.bias", {F}), up.get(p + "layernorm_after.weight", {D}),
                  up.get(p + "layernorm_after.bias", {D}), F, L.w1_f, L.s1, L.b1_f);
         }
@@ -1742,6 +1826,7 @@ void commit_weights(mocr_engine* e) {
     e->host_w.clear();
     e->host_shape.clear();
     e->committed = true;
+    if (c.dtype == MOCR_BF16 && !ln_gb.g.empty()) calibrate_ln_fold(e, ln_gb);
 }
 
 void compute_geometry(mocr_engine* e) {
@@ -1809,7 +1894,7 @@ void allocate_lanes(mocr_engine* e) {
     compute_geometry(e);
     e->latent = e->cfg.dtype == MOCR_BF16 && !(e->cfg.flags & MOCR_FLAG_CLASSIC_ATTENTION);
     e->fp8attn = e->latent && (e->cfg.flags & MOCR_FLAG_FP8_ATTENTION);
-    e->lat_tk = (e->cfg.flags & MOCR_FLAG_LATENT_TILE32) ? 32 : env_int("MOCR_LAT_TK", 16);
+    e->lat_tk = (e->cfg.flags & MOCR_FLAG_LATENT_TILE32) ? 32 : env_int("MOCR_LAT_TK", 17);
     // Small batches of a latent engine take the classic kernels: the persistent latent kernel walks a sequence's key
     // tiles serially on ONE CU (~20 us per call whatever the batch), the classic one spreads a row over 12 blocks.
     // Measured (r01, 300 tokens): 8 rows 36 vs 73 ms, 64 rows 50 vs 80 ms, 256 rows 111 vs 116 ms; r02, both paths with
@@ -2335,6 +2420,20 @@ int mocr_set_generate_max_length(mocr_engine* e, int32_t max_len) {
     });
 }
 
+int mocr_ln_fold_state(mocr_engine* e, float* noise_ratio) {
+    if (!e) return 0;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (noise_ratio) *noise_ratio = e->fold_ratio;
+    if (e->cfg.dtype != MOCR_BF16 || (e->cfg.flags & MOCR_FLAG_NO_LN_FOLD)) return 0;
+    return (e->fold_ok || (e->cfg.flags & MOCR_FLAG_FORCE_LN_FOLD)) ? 1 : 0;
+}
+
+int64_t mocr_decode_slot_steps(mocr_engine* e) {
+    if (!e) return 0;
+    std::lock_guard<std::mutex> lk(e->mu);
+    return e->n_slot_steps;
+}
+
 int64_t mocr_compaction_count(mocr_engine* e) {
     if (!e) return 0;
     std::lock_guard<std::mutex> lk(e->mu);
@@ -2493,7 +2592,7 @@ int mocr_op_latent_attention(mocr_engine* e, const void* d_qt, const void* d_x, 
         launch_latent(e, false, p);
         HIPCHECK(hipStreamSynchronize(e->stream));
         if (p.dbg) {
-            unsigned long long h[8];
+            unsigned long long h[40];
             HIPCHECK(hipMemcpy(h, p.dbg, sizeof(h), hipMemcpyDeviceToHost));
             if (env_int("MOCR_LAT_DUMP", 0)) {
                 std::vector<float> f(1024);
@@ -2501,7 +2600,9 @@ int mocr_op_latent_attention(mocr_engine* e, const void* d_qt, const void* d_x, 
                 FILE* fp = fopen("gpurun_out/lat_dump.bin", "wb");
                 if (fp) { fwrite(f.data(), 4, 1024, fp); fclose(fp); }
             }
-            fprintf(stderr, "[lat stamps, cycles] wait+issue %llu  S %llu  exchange %llu  softmax %llu  PX %llu  other %llu\n", h[0], h[1], h[2], h[3], h[4], h[5]);
+            for (int w = 0; w < 4; ++w)
+                fprintf(stderr, "[lat stamps, cycles, block 0 wave %d] wait+issue %llu  S %llu  exchange %llu  softmax %llu  PX %llu  loop/Qt %llu  rowend-b1 %llu  stage-b2 %llu  store %llu\n",
+                        w, h[10 * w], h[10 * w + 1], h[10 * w + 2], h[10 * w + 3], h[10 * w + 4], h[10 * w + 5], h[10 * w + 6], h[10 * w + 7], h[10 * w + 8]);
         }
     });
 }

@@ -270,8 +270,8 @@ __global__ __launch_bounds__(256, 2) void enc_attn_mfma_kernel(const bf16_t* __r
 //     then stand for keys {4g+j of tile 2u, 4g+j of tile 2u+1}); the A operand follows the same key order by reading V
 //     column-wise with ds_read_b64_tr_b16: rows 32u + 4g .. +3 and 32u + 16 + 4g .. +3 of the row-major image - no
 //     transposed copy of V anywhere.
-//   Keys 197 .. 207: rows 197-199 are whatever follows in the QKV matrix (finite; the buffers are padded), rows 200-207 are
-//   zeroed once; their scores are set to -inf, so their probabilities are exactly 0.
+//   Keys 197 .. 207: rows 197-199 are copies of key 196 (the copy's source row is clamped: nothing behind an image's 197
+//   rows is read), rows 200-207 are zeroed once; their scores are set to -inf, so their probabilities are exactly 0.
 // ------------------------------------------------------------------------------------------------
 #define EA2_ROWS 208
 #define EA2_LDS (2 * EA2_ROWS * 128)
@@ -309,7 +309,9 @@ __global__ __launch_bounds__(256, 3) void enc_attn2_kernel(const bf16_t* __restr
         for (int pc = wave; pc < ((ablate & 8) ? 0 : 25); pc += 4) {
             const int row = pc * 8 + prow;
             const int c = pch ^ ((row >> 1) & 7);
-            const bf16_t* src = base + (size_t)row * ld_qkv + c * 8;
+            // rows 197 .. 199 of the LDS image: a second copy of key 196 (their scores are -inf, their probabilities exactly 0, but
+            // 0 x whatever FOLLOWS the image's rows in memory must stay finite - and for the last image nothing follows)
+            const bf16_t* src = base + (size_t)(row < ENC_S ? row : ENC_S - 1) * ld_qkv + c * 8;
             glds16(src + D, sK + pc * 1024);
             glds16(src + 2 * D, sV + pc * 1024);
         }

@@ -173,6 +173,15 @@ __device__ __forceinline__ void wait_vm_newer(int newer) {
 }
 #undef LAT_VM_CASE
 
+// One int through the SCALAR cache (the address is wave-uniform).  Written as asm because hipcc turns `rowmap[row]` into a
+// vector load followed by s_waitcnt vmcnt(0) + v_readfirstlane - a drain of the DMA ring at every row (the pointer is not
+// provably invariant, so it will not use s_load by itself).
+__device__ __forceinline__ int lat_sload(const int* p) {
+    int v;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    return v;
+}
+
 // request one tile: DMA wave w (0..2) takes the pieces pc = w + 3i (1 KiB = 64 consecutive 16-byte chunks of the
 // tile image) with pc < np.  A full tile is np = 48 pieces (16 DMA instructions per DMA wave); a sequence's last tile
 // asks only for the pieces that hold its valid keys (src_off: this lane's 16 source offsets).  The branch is
@@ -228,7 +237,7 @@ __global__ __launch_bounds__(256, LatCfg<TK>::BLOCKS_PER_CU) void latent_attn_ke
     // (MFMA write -> v_accvgpr_read) and silently corrupts the last accumulator.
 #ifdef MOCR_LAT_STAMPS
     unsigned long long* const P_dbg = p.dbg;
-    unsigned long long tsum[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+    unsigned long long tsum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
 #define STAMP(k)                                                                                   \
     {                                                                                              \
         unsigned long long tn;                                                                     \
@@ -287,7 +296,7 @@ __global__ __launch_bounds__(256, LatCfg<TK>::BLOCKS_PER_CU) void latent_attn_ke
     const bf16_t* const q_lane = P_qt + (size_t)(l15 < P_heads ? l15 : l15 - P_heads) * LAT_D + 192 * wave + 8 * g;
 #define Q_PTR(row) (q_lane + (size_t)(row) * 16 * LAT_D)
     // keys of sequence `row`: its own slot of x, or (r04, compacted batches) the slot its rowmap entry names
-#define X_ROW(row) (P_x + (size_t)(P_rowmap ? P_rowmap[row] : (row)) * P_xstride)
+#define X_ROW(row) (P_x + (size_t)(P_rowmap ? lat_sload(P_rowmap + (row)) : (row)) * P_xstride)
 
     int cr = blockIdx.x;                 // sequence being consumed
     if (cr >= P_rows) return;
@@ -546,10 +555,12 @@ __global__ __launch_bounds__(256, LatCfg<TK>::BLOCKS_PER_CU) void latent_attn_ke
         // ---- finish the row: normalise, stage through LDS (12 heads x 768 bf16 = 18 KiB in the ring slot the last tile
         // freed), store with 18 full 16-byte accesses per lane of wave 3
 #ifndef MOCR_LAT_NOEPI       // timing experiment only
+        STAMP(5)   // loop exit
         if (l15 == 0) sAl[16 + 4 * g + wave] = l_run;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        STAMP(6)   // row end: first barrier
         float inv[4];
         {
             uint4 l4;     // inline asm for the same reason as the alpha/P read above
@@ -574,6 +585,7 @@ __global__ __launch_bounds__(256, LatCfg<TK>::BLOCKS_PER_CU) void latent_attn_ke
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        STAMP(7)   // row end: normalise + stage + second barrier
         {
             // 1152 chunks of 16 B = 12 heads x 1536 B, contiguous in the output: wave 3 moves them all, lane l the
             // chunks l + 64k, k = 0..17, six at a time.  Its queue holds only its own Qt prefetch and stores: the
@@ -599,6 +611,7 @@ __global__ __launch_bounds__(256, LatCfg<TK>::BLOCKS_PER_CU) void latent_attn_ke
                 }
             }
         }
+        STAMP(8)   // row end: the stores (wave 3)
 #endif
         // ---- the next row's Qt: prove the prefetch landed, then (and only then) copy it.  With >= 3 tiles
         // the wait for tile 2 (requested after the prefetch) already proved it; shorter rows wait here
@@ -612,8 +625,8 @@ __global__ __launch_bounds__(256, LatCfg<TK>::BLOCKS_PER_CU) void latent_attn_ke
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef MOCR_LAT_STAMPS
-    if (P_dbg && blockIdx.x == 0 && tid == 0)
-        for (int k = 0; k < 6; ++k) P_dbg[k] = tsum[k];
+    if (P_dbg && blockIdx.x == 0 && lane == 0)
+        for (int k = 0; k < 10; ++k) P_dbg[10 * wave + k] = tsum[k];
 #endif
 #undef STAMP
 #undef ISSUE_BEGIN

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256, 1) void latent_attn_fp8_kernel(Latent8Params p
     bf16_t* const P_out = p.out;
     const long long P_xstride = p.x_batch_stride;
     const int* const P_rowmap = p.rowmap;
-#define X8_SLOT(row) ((size_t)(P_rowmap ? P_rowmap[row] : (row)))      // wave-uniform: a scalar load, no VMEM
+#define X8_SLOT(row) ((size_t)(P_rowmap ? lat_sload(P_rowmap + (row)) : (row)))      // wave-uniform: a scalar load (asm: kernels_latent.h), no VMEM
     const int P_rows = p.rows, P_heads = p.heads;
     const float P_sx = p.sx;
     float* sS = reinterpret_cast<float*>(smem + LAT8_NST * LAT8_TILE_BYTES);       // [4][16][64] partial scores (16 KiB)

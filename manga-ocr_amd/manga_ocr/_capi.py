@@ -58,6 +58,8 @@ SYMBOLS = {
     "mocr_recognize_regions": (C.c_int, [_P, C.POINTER(MocrImage), C.c_int32, C.POINTER(MocrRegion), C.c_int32, _P, _P]),
     "mocr_graph_count": (C.c_int, [_P]),
     "mocr_compaction_count": (C.c_int64, [_P]),
+    "mocr_decode_slot_steps": (C.c_int64, [_P]),
+    "mocr_ln_fold_state": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "mocr_device_memory": (C.c_int, [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "mocr_preprocess": (C.c_int, [_P, C.POINTER(MocrImage), C.c_int32, _P]),
     "mocr_recognize_device": (C.c_int, [_P, _P, C.c_int32, _P, _P]),

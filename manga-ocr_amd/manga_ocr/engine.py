@@ -168,6 +168,17 @@ class Engine:
     def graph_count(self) -> int:
         return int(self.lib.mocr_graph_count(self._h))
 
+    def ln_fold_state(self) -> Tuple[bool, float]:
+        """(folds, noise_ratio): whether fat bf16 batches run with the encoder's LayerNorms folded into the GEMMs, and the
+        input-rounding noise ratio commit measured on this checkpoint's residual stream (include/mocr.h)."""
+        r = C.c_float(0.0)
+        on = self.lib.mocr_ln_fold_state(self._h, C.byref(r))
+        return bool(on), float(r.value)
+
+    def decode_slot_steps(self) -> int:
+        """Decode slots x steps enqueued so far (what the decode launches were sized for, in row-steps)."""
+        return int(self.lib.mocr_decode_slot_steps(self._h))
+
     def compaction_count(self) -> int:
         """Row compactions performed so far: unfinished rows moved to the first decode slots between chunks of steps."""
         return int(self.lib.mocr_compaction_count(self._h))

@@ -35,18 +35,27 @@ class ResultsJournal:
                         continue
                     try:
                         rec = json.loads(line)
-                        self._done[rec["key"]] = rec["text"]
+                        self._done[self._k(rec["key"])] = rec["text"]
                     except (ValueError, KeyError, TypeError):
                         self.torn_records += 1          # a record cut short by a crash: its crop is decoded again
+        # never append behind half a line: a crash may have cut a record anywhere - including exactly in front of its trailing
+        # newline, which leaves a record that parses and a file that does not end in one
+        ends_clean = True
+        if os.path.exists(path) and os.path.getsize(path) > 0:
+            with open(path, "rb") as fb:
+                fb.seek(-1, os.SEEK_END)
+                ends_clean = fb.read(1) == b"\n"
         self._fh = open(path, "a", encoding="utf-8")
-        if self.torn_records:                            # never append behind half a record
+        if not ends_clean:
             self._fh.write("\n")
             self._fh.flush()
 
     # ------------------------------------------------------------------ container protocol
     @staticmethod
     def _k(key: Hashable) -> str:
-        return key if isinstance(key, str) else json.dumps(key, sort_keys=True, ensure_ascii=False)
+        """In-memory key: always the JSON form, so that the int 1 ("1") and the str "1" ("\"1\"") stay two crops; a record
+        stores the key as the JSON VALUE itself (a str key reads back as that str, a tuple as a list: the same form again)."""
+        return json.dumps(key, sort_keys=True, ensure_ascii=False)
 
     def __contains__(self, key: Hashable) -> bool:
         return self._k(key) in self._done
@@ -64,7 +73,7 @@ class ResultsJournal:
             for key, text in zip(keys, texts):
                 k = self._k(key)
                 self._done[k] = text
-                self._fh.write(json.dumps({"key": k, "text": text}, ensure_ascii=False) + "\n")
+                self._fh.write(json.dumps({"key": json.loads(k), "text": text}, ensure_ascii=False) + "\n")
             self._fh.flush()
             if self.fsync:
                 os.fsync(self._fh.fileno())
@@ -89,7 +98,7 @@ class ResultsJournal:
             tmp = self.path + ".tmp"
             with open(tmp, "w", encoding="utf-8") as fh:
                 for k, text in self._done.items():
-                    fh.write(json.dumps({"key": k, "text": text}, ensure_ascii=False) + "\n")
+                    fh.write(json.dumps({"key": json.loads(k), "text": text}, ensure_ascii=False) + "\n")
                 fh.flush()
                 os.fsync(fh.fileno())
             self._fh.close()

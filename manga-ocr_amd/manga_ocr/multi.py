@@ -486,9 +486,14 @@ class MultiGpuEngine:
         n = len(images)
         if n == 0:
             return np.zeros((0, self.max_len), np.int32), np.zeros(0, np.int32)
+        if rotate is not None:
+            # checked HERE: a short or out-of-range list would otherwise fail inside a child, chunk by chunk, and come back as
+            # obscure per-row errors after many re-dealt decodes
+            rotate = [int(r) for r in rotate]
+            if len(rotate) != n or any(r not in (0, 1, 2) for r in rotate):
+                raise ValueError(f"recognize_images: rotate needs one code in {{0, 1, 2}} per image ({n} images, {len(rotate)} codes)")
         descs, size, fill = self._pack(images)
-        return self._run(n, size, fill, dict(kind="images", descs=descs, bgr=bool(bgr),
-                                             rotate=[int(r) for r in rotate] if rotate is not None else None))
+        return self._run(n, size, fill, dict(kind="images", descs=descs, bgr=bool(bgr), rotate=rotate))
 
     def recognize_regions(self, pages, regions, bgr: bool = True) -> Tuple[np.ndarray, np.ndarray]:
         regs = [tuple(int(v) for v in r) for r in regions]

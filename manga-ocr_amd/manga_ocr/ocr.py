@@ -229,6 +229,8 @@ class MangaOcr:
         crops = list(crops_bgr)
         rot = None
         if orientations is not None:
+            if len(orientations) != len(crops):        # zip() would truncate silently: a short list must not cost a decode
+                raise ValueError(f"recognize_bgr: {len(crops)} crops but {len(orientations)} orientations")
             rot = [rotation_code(c.shape[0], c.shape[1], o) for c, o in zip(crops, orientations)]
         return [ids_to_text(self.vocab, r) for r in self.recognize_ids(crops, bgr=True, rotate=rot)]
 

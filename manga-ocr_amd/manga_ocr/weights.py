@@ -139,7 +139,8 @@ def tensor_table(spec: ModelSpec = DEFAULT_SPEC) -> List[TensorRow]:
 
 def synthetic_weights(seed: int = 0, spec: ModelSpec = DEFAULT_SPEC, *, std: float = 0.02,
                       bias_std: float = 0.02, ln_std: float = 0.1, tie_lm_head: bool = True,
-                      eos_bias: float = 0.0, logit_scale: float = 1.0, vocab_bias_std: float = 0.0) -> Dict[str, np.ndarray]:
+                      eos_bias: float = 0.0, logit_scale: float = 1.0, vocab_bias_std: float = 0.0,
+                      hostile=False) -> Dict[str, np.ndarray]:
     """Deterministic synthetic parameters (float32).
 
     One ``numpy.random.RandomState(seed)`` stream (frozen algorithm), tensors drawn
@@ -158,6 +159,15 @@ def synthetic_weights(seed: int = 0, spec: ModelSpec = DEFAULT_SPEC, *, std: flo
     N(0, vocab_bias_std^2) term (its own RandomState(seed + 7919) stream) to the fp32
     vocabulary bias: exact in every engine, it widens the top-2 margins relative to the
     bf16 noise of the matrix products - the widened-margin weights of the bf16 id tests.
+    ``hostile`` (r04) gives the ENCODER the residual-stream statistics of trained ViTs instead of the near-normalised stream
+    plain N(0, std^2) weights produce (its own RandomState(seed + 104729) stream, applied after the draws above):
+    LayerNorm gains ~ U(0.2, 3) and shifts ~ N(0, 0.5^2); a DC offset of +2.0 (about 6 sigma of the embedded patches) on
+    every channel of the patch-embedding bias and the CLS token; two massive-activation channels (HOSTILE_CHANNELS) at
+    +100 (about 300 sigma).  Nothing in a pre-LN ViT ever removes what the embeddings put on the stream, so all of it
+    reaches every LayerNorm - the inputs on which shortcuts that round the raw stream to bf16 are to be judged.
+    ``hostile="dc"``: the same gains / shifts and a DC offset of +4.0 WITHOUT the massive channels - the row mean is then
+    several times the row's spread at every LayerNorm (with massive channels the spread is theirs), the case in which
+    rounding the raw stream costs precision where rounding the normalised stream does not.
     """
     rs = np.random.RandomState(seed)
     out: Dict[str, np.ndarray] = {}
@@ -187,7 +197,30 @@ def synthetic_weights(seed: int = 0, spec: ModelSpec = DEFAULT_SPEC, *, std: flo
     if eos_bias != 0.0:
         out[lm_b] = out[lm_b].copy()
         out[lm_b][spec.eos_id] += np.float32(eos_bias)
+    if hostile:
+        hs = np.random.RandomState(seed + 104729)
+        for name, shape, kind in tensor_table(spec):
+            if not name.startswith("encoder."):
+                continue
+            if kind == "g":
+                out[name] = hs.uniform(0.2, 3.0, size=shape).astype(np.float32)
+            elif kind == "beta":
+                out[name] = (0.5 * hs.standard_normal(shape)).astype(np.float32)
+        pb = "encoder.embeddings.patch_embeddings.projection.bias"
+        cls = "encoder.embeddings.cls_token"
+        dc_only = hostile == "dc"
+        out[pb] = out[pb] + np.float32(HOSTILE_DC_ONLY if dc_only else HOSTILE_DC)
+        out[cls] = out[cls] + np.float32(HOSTILE_DC_ONLY if dc_only else HOSTILE_DC)
+        for ch in (() if dc_only else HOSTILE_CHANNELS):
+            out[pb][ch] += np.float32(HOSTILE_MASSIVE)
+            out[cls][0, 0, ch] += np.float32(HOSTILE_MASSIVE)
     return out
+
+
+HOSTILE_DC = 2.0
+HOSTILE_DC_ONLY = 4.0
+HOSTILE_MASSIVE = 100.0
+HOSTILE_CHANNELS = (77, 500)
 
 
 # --------------------------------------------------------------------------------------

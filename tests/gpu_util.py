@@ -24,18 +24,18 @@ def crops(seed, n):
 
 
 @functools.lru_cache(maxsize=None)
-def weights(seed=0, eos_bias=0.0, vocab_bias_std=0.0):
-    return synthetic_weights(seed, eos_bias=eos_bias, vocab_bias_std=vocab_bias_std)
+def weights(seed=0, eos_bias=0.0, vocab_bias_std=0.0, hostile=False):
+    return synthetic_weights(seed, eos_bias=eos_bias, vocab_bias_std=vocab_bias_std, hostile=hostile)
 
 
 @functools.lru_cache(maxsize=None)
-def engine(dtype="fp32", seed=0, eos_bias=0.0, max_batch=8, flags=0, lanes=1, auto_path=False, vocab_bias_std=0.0):
+def engine(dtype="fp32", seed=0, eos_bias=0.0, max_batch=8, flags=0, lanes=1, auto_path=False, vocab_bias_std=0.0, hostile=False):
     """bf16 engines of the tests run the latent attention at every batch size (flag 64) unless they ask for the classic
     kernels (flag 8) or for the product's automatic choice (auto_path: classic up to 384 rows)."""
     from manga_ocr.engine import Engine
     if dtype == "bf16" and not auto_path and not (flags & 8):
         flags |= 64
-    return Engine(weights(seed, eos_bias, vocab_bias_std), DEFAULT_SPEC, dtype=dtype, device=0, max_batch=max_batch, flags=flags, lanes=lanes)
+    return Engine(weights(seed, eos_bias, vocab_bias_std, hostile), DEFAULT_SPEC, dtype=dtype, device=0, max_batch=max_batch, flags=flags, lanes=lanes)
 
 
 def drop_engines():
@@ -46,9 +46,9 @@ def drop_engines():
 
 
 @functools.lru_cache(maxsize=None)
-def oracle(seed=0, eos_bias=0.0, vocab_bias_std=0.0):
+def oracle(seed=0, eos_bias=0.0, vocab_bias_std=0.0, hostile=False):
     from oracle.mocr_oracle import Oracle
-    return Oracle(weights(seed, eos_bias, vocab_bias_std), DEFAULT_SPEC)
+    return Oracle(weights(seed, eos_bias, vocab_bias_std, hostile), DEFAULT_SPEC)
 
 
 def bf16_round(a: np.ndarray) -> np.ndarray:

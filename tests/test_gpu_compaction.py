@@ -8,7 +8,7 @@ Checked here, through the C ABI:
 
 * fp32 parity mode: the compacted batch's ids are the transformers golden ids (``tests/golden/early_eos_seed1.npz``) for
   every copy of the six golden crops, and bit-identical to an uncompacted run (``MOCR_FLAG_NO_COMPACTION``);
-* bf16, every attention path (latent 16- and 32-key tiles, classic, fp8): compacted == uncompacted, ids and lengths,
+* bf16, every attention path (the latent kernel and its A/B partner, classic, fp8): compacted == uncompacted, ids and lengths,
   bit for bit - the batch keeps the kernel regime it started with, so no summation order changes;
 * the compactions really happen (``mocr_compaction_count``), on one lane and with two lanes in flight.
 """
@@ -57,8 +57,8 @@ def test_fp32_compacted_batch_gives_the_golden_early_eos_ids():
 
 
 @pytest.mark.parametrize("name,rows,flags", [
-    ("latent, 16-key tiles", 640, 64),
-    ("latent, 32-key tiles", 640, 64 | 1024),
+    ("latent", 640, 64),
+    ("latent, r03 kernel shape (32-key tiles)", 640, 64 | 1024),
     ("latent, fused query kernel", 1280, 64),
     ("classic (automatic choice at 96 rows)", 96, 0),
     ("fp8 attention", 640, 64 | 128),

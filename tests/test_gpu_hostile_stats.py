@@ -1,0 +1,111 @@
+"""The bf16 shortcuts on the residual-stream statistics of trained ViTs (r04).
+
+Every other parity test uses N(0, 0.02^2) weights with LayerNorm gains near 1: the residual stream stays near-normalised.
+Trained ViTs carry DC offsets and massive-activation channels of 10^2 - 10^3 sigma, and two of the engine's bf16 choices
+depend on exactly that: the LayerNorms folded into the GEMMs feed bf16(x) - the raw stream - into the matrix cores and
+finish with a one-pass variance (``csrc/kernels_gemm_pers.h``), and ``gelu_fast`` replaces the erf form.
+``synthetic_weights(3, hostile=True)`` builds such a stream (gains U(0.2, 3), shifts N(0, 0.5^2), +2.0 on every channel =
+6-7 sigma of the content, two channels at +100 = 300 sigma: ``tests/golden/hostile_seed3.npz`` records the statistics
+transformers itself saw), ``hostile="dc"`` one with the DC offset alone (+4.0: the row mean several times the row's spread
+at every LayerNorm), and the goldens are transformers' own outputs (``make_goldens.py --hostile [--dc]``), not only the
+oracle's.  The engine decides per checkpoint: ``mocr_commit_weights`` measures the rounding-noise ratio of the two forms on
+probe crops and folds only where it is <= 1.5 (``mocr_ln_fold_state``).
+
+Arithmetic: ``TF/models/vit/modeling_vit.py:266-286`` (pre-LN block), ``TF/models/bert/modeling_bert.py:282-351``.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from gpu_util import crops, engine, oracle, report
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+# kind -> (synthetic_weights(3, hostile=...), golden file): "massive" = DC offset + two massive-activation channels (the row's
+# spread is then theirs); "dc" = the DC offset alone, twice as large: |row mean| several times the row's spread at EVERY LayerNorm
+KINDS = {"massive": (True, "hostile_seed3.npz"), "dc": ("dc", "hostile_dc_seed3.npz")}
+NO_LN_FOLD, FORCE_LN_FOLD = 512, 8192
+ROWS = 256
+
+
+def _gold(kind):
+    return np.load(os.path.join(GOLDEN_DIR, KINDS[kind][1]))
+
+
+def _batch():
+    """The 8 golden crops first; the rest only fills the batch up to where the encoder takes the persistent kernels."""
+    return np.concatenate([crops(2024, 8), crops(2025, ROWS - 8)])
+
+
+def _enc_err(eng, dg, gold):
+    got = eng.encode(dg, ROWS).astype(np.float64)[:8][:, gold["tok_rows"], :]
+    ref = gold["final_rows"].astype(np.float64)
+    scale = np.abs(ref).max()
+    assert np.isfinite(got).all()
+    return np.abs(got - ref).max() / scale, np.sqrt(((got - ref) ** 2).mean()) / scale
+
+
+@pytest.mark.parametrize("kind", list(KINDS))
+def test_oracle_matches_the_hostile_goldens(kind):
+    """(CPU arithmetic, kept here with the case it belongs to) the oracle against transformers on the hostile weights."""
+    gold = _gold(kind)
+    o = oracle(seed=3, hostile=KINDS[kind][0])
+    enc = o.encode(o.preprocess_gray(crops(2024, 8)))
+    ref = gold["final_rows"]
+    assert np.abs(enc.numpy()[:, gold["tok_rows"], :] - ref).max() <= 2e-4 * np.abs(ref).max()
+    ids, _ = o.generate(enc, max_len=24, return_logits=True)
+    np.testing.assert_array_equal(np.asarray(ids)[:, :24], gold["ids_len24"])
+
+
+@pytest.mark.parametrize("kind", list(KINDS))
+def test_bf16_encoder_on_a_hostile_residual_stream(kind):
+    """Final encoder rows of the 8 golden crops inside a 256-crop batch (persistent GEMMs) against transformers: the default
+    engine, the LayerNorm launches (MOCR_FLAG_NO_LN_FOLD) and the fold forced on (MOCR_FLAG_FORCE_LN_FOLD).  The default must
+    be as accurate as the separate launches: mocr_commit_weights measures the stream (mocr_ln_fold_state) and keeps the
+    LayerNorms as launches where rounding the raw stream would cost precision ("dc": ratio > 1.5); where the row's spread is
+    as large as its mean ("massive") the fold holds and stays on."""
+    gold = _gold(kind)
+    dg = torch.from_numpy(_batch()).cuda()
+    torch.cuda.synchronize()
+    res = {}
+    state = None
+    for name, flags in (("default", 0), ("separate LayerNorm launches", NO_LN_FOLD), ("fold forced on", FORCE_LN_FOLD)):
+        eng = engine("bf16", seed=3, hostile=KINDS[kind][0], max_batch=ROWS, flags=flags)
+        if name == "default":
+            state = eng.ln_fold_state()
+        res[name] = _enc_err(eng, dg, gold)
+    report(f"bf16 encoder, hostile residual stream '{kind}': commit-time noise ratio {state[1]:.2f} -> fold {'ON' if state[0] else 'OFF'}; "
+           "(|row mean| / content std " +
+           f"{gold['stream_row_mean_over_info_std'][0]:.1f} -> {gold['stream_row_mean_over_info_std'][-1]:.1f}, massive channels "
+           f"{gold['stream_channel_dc_max'].max():.0f} sigma), max / rms error over |ref|max vs transformers: " +
+           "; ".join(f"{k}: {v[0]:.3e} / {v[1]:.3e}" for k, v in res.items()))
+    e_def, e_sep = res["default"], res["separate LayerNorm launches"]
+    assert e_def[0] <= max(1.5 * e_sep[0], 2e-2) and e_def[1] <= 1.3 * e_sep[1]
+    assert e_sep[0] <= 4e-2
+    assert state[0] == (kind == "massive") and (state[1] > 1.5) == (kind == "dc")
+    benign = engine("bf16", max_batch=ROWS).ln_fold_state()            # the plain synthetic weights of every other test: folded
+    assert benign[0] and 0.9 < benign[1] < 1.5
+
+
+@pytest.mark.parametrize("kind", list(KINDS))
+def test_bf16_teacher_forced_logits_on_hostile_weights(kind):
+    """Teacher-forced logits of the 8 golden crops (inside the 256-crop batch, 23 steps) against transformers' own logit
+    columns: the bf16 tolerance of the benign-weights tests must hold."""
+    gold = _gold(kind)
+    dg = torch.from_numpy(_batch()).cuda()
+    torch.cuda.synchronize()
+    T = 23
+    forced = np.zeros((ROWS, T + 1), np.int32)
+    forced[:8] = gold["ids_len24"][:, :T + 1]
+    forced[8:] = gold["ids_len24"][0, :T + 1]
+    eng = engine("bf16", seed=3, hostile=KINDS[kind][0], max_batch=ROWS, auto_path=True)
+    got = eng.decode_logits(dg, ROWS, forced[:, :T])[:8][:, :, gold["vocab_cols"]]
+    ref = gold["logits_cols"][:, :T]
+    d = np.abs(got - ref)
+    gap = gold["logits_top2_gap"][:, :T]
+    report(f"teacher-forced logits bf16 on hostile weights '{kind}' (8 golden crops in a {ROWS}-row batch, {T} steps, 64 vocabulary columns) vs "
+           f"transformers: max abs err {d.max():.3e}, mean {d.mean():.3e}; smallest reference top-2 margin {gap.min():.3e}")
+    assert np.isfinite(got).all() and d.max() <= 3e-2

@@ -58,7 +58,7 @@ def test_a_failing_chunk_keeps_what_was_recorded_before_it(tmp_path):
         with pytest.raises(RuntimeError):
             j.run(list(range(10, 16)), list(range(10, 16)), rec, chunk=2)
     with ResultsJournal(path) as j:
-        assert sorted(j._done) == ["10", "11"] or sorted(j._done) == [json.dumps(10), json.dumps(11)]
+        assert sorted(j._done) == [json.dumps(10), json.dumps(11)]
 
 
 def test_compact_rewrites_one_record_per_key_atomically(tmp_path):
@@ -79,3 +79,29 @@ def test_wrong_result_count_is_an_error(tmp_path):
             j.run([1, 2], ["a", "b"], lambda items: ["only one"])
         with pytest.raises(ValueError):
             j.run([1], ["a", "b"], lambda items: items)
+
+
+def test_a_crash_that_cut_only_the_trailing_newline_loses_nothing(tmp_path):
+    """r03 advisor: a complete last record without its newline parses - the next append must still start a new line, or the
+    next load drops BOTH records."""
+    from manga_ocr.journal import ResultsJournal
+    p = str(tmp_path / "j.jsonl")
+    with ResultsJournal(p) as j:
+        j.record(["a", "b"], ["A", "B"])
+    raw = open(p, "rb").read()
+    assert raw.endswith(b"\n")
+    open(p, "wb").write(raw[:-1])                      # the crash
+    with ResultsJournal(p) as j:
+        assert j.torn_records == 0 and j.get("b") == "B"
+        j.record(["c"], ["C"])
+    with ResultsJournal(p) as j:
+        assert j.torn_records == 0 and [j.get(k) for k in "abc"] == ["A", "B", "C"]
+
+
+def test_int_and_str_keys_do_not_shadow_each_other(tmp_path):
+    from manga_ocr.journal import ResultsJournal
+    p = str(tmp_path / "j.jsonl")
+    with ResultsJournal(p) as j:
+        j.record([1, "1", (2, "x")], ["int", "str", "tuple"])
+    with ResultsJournal(p) as j:
+        assert j.get(1) == "int" and j.get("1") == "str" and j.get((2, "x")) == "tuple" and len(j) == 3

@@ -100,3 +100,21 @@ def test_teacher_forced_logits_equal_free_running(oracle0, enc0):
     ids, logits = oracle0.generate(enc0[0][:2], max_len=12, return_logits=True)
     _, tf_logits = oracle0.generate(enc0[0][:2], return_logits=True, forced_ids=ids[:, :-1])
     np.testing.assert_allclose(tf_logits, logits, rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("kind,fname", [(True, "hostile_seed3.npz"), ("dc", "hostile_dc_seed3.npz")])
+def test_oracle_on_hostile_residual_streams(golden_dir, kind, fname):
+    """r04: the oracle against transformers on weights that give the encoder the residual-stream statistics of trained ViTs
+    (synthetic_weights(3, hostile=...): LayerNorm gains U(0.2, 3), DC offsets, massive-activation channels) - the goldens
+    the bf16 shortcuts are judged by (tests/test_gpu_hostile_stats.py)."""
+    g = np.load(os.path.join(golden_dir, fname))
+    o = Oracle(synthetic_weights(3, hostile=kind), DEFAULT_SPEC)
+    enc = o.encode(o.preprocess_gray(crops(2024, 8)))
+    ref = g["final_rows"]
+    assert np.abs(enc.numpy()[:, g["tok_rows"], :] - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+    np.testing.assert_allclose(enc.double().sum(dim=(1, 2)).numpy(), g["final_sum"], rtol=0, atol=2e-3 * np.abs(ref).max())
+    ids, logits = o.generate(enc, max_len=24, return_logits=True)
+    np.testing.assert_array_equal(np.asarray(ids)[:, :24], g["ids_len24"])
+    assert np.abs(logits[:, :23][:, :, g["vocab_cols"]] - g["logits_cols"][:, :23]).max() <= 2e-4
+    # what makes the streams hostile, as transformers saw it: recorded, not re-derived
+    assert g["stream_row_mean_over_info_std"][0] > 5 and (fname != "hostile_seed3.npz" or g["stream_channel_dc_max"].max() > 100)

@@ -29,7 +29,8 @@ import shutil
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 CLASSES = [  # (substring of the kernel symbol, bench.py's class name)
-    ("latent_attn_kernel<true>", "lat_attn_self"), ("latent_attn_kernel<false>", "lat_attn_cross"),
+    ("latent_attnT_kernel<true>", "lat_attn_self"), ("latent_attnT_kernel<false>", "lat_attn_cross"),      # r04 default
+    ("latent_attn_kernel<true", "lat_attn_self"), ("latent_attn_kernel<false", "lat_attn_cross"),
     ("latent_attn_fp8_kernel<true>", "lat8_attn_self"), ("latent_attn_fp8_kernel<false>", "lat8_attn_cross"),
     ("dec_qqt_kernel", "dec_qqt"), ("enc_attn_mfma_kernel", "enc_attn_mfma"), ("enc_attn2_kernel", "enc_attn_mfma"),
     ("layernorm_kernel", "layernorm"), ("ln_prep_kernel", "ln_prep"),
@@ -88,6 +89,7 @@ def main():
     ap.add_argument("--stats")
     ap.add_argument("--fetch")
     ap.add_argument("--write")
+    ap.add_argument("--sq", help="directory of the SQ pass (--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_WAIT_INST_LDS ...): <round>_mfma_util.json")
     ap.add_argument("--note", default="")
     ap.add_argument("--rows", type=int, required=True, help="rows of the internal batches the passes ran")
     a = ap.parse_args()
@@ -125,6 +127,29 @@ def main():
                 ent["traffic_over_algorithmic"] = ent["traffic_bytes_per_launch"] / alg
             by[c] = ent
         json.dump(res, open(path, "w"), indent=1)
+    if a.sq:
+        # one row per (dispatch, counter): per kernel class the mean of every counter.  MFMA utilisation = the matrix pipes' busy
+        # cycles over the cycles they could have been busy: SQ_VALU_MFMA_BUSY_CYCLES (summed over the chip's SIMDs, in cycles)
+        # / (4 SIMDs x CUs x the kernel's cycles), the kernel's cycles taken as GRBM-free: SQ_BUSY_CYCLES (quad-cycle units
+        # of the busy SEs, MI355X_MICROARCH.md 'rocprofv3 PMC slots') - both ratios are reported raw next to the recipe.
+        agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
+        for r in csv.DictReader(open(find(a.sq, "counter_collection.csv"))):
+            c = klass(r["Kernel_Name"])
+            if c:
+                e = agg[c][r["Counter_Name"]]
+                e[0] += 1
+                e[1] += float(r["Counter_Value"])
+        res = {"note": a.note, "rows": a.rows,
+               "recipe": "rocprofv3 --pmc <SQ counters> (a pass of its own, no trace) of `python bench.py --steps 10 --warmup 0 --lanes 1 --only-timed`; "
+                         "per kernel class the mean per dispatch; mfma_busy_over_busy = SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES as the counters come",
+               "classes": {}}
+        for c, d in agg.items():
+            ent = {k: v[1] / v[0] for k, v in d.items()}
+            ent["dispatches"] = max(v[0] for v in d.values())
+            if ent.get("SQ_BUSY_CYCLES"):
+                ent["mfma_busy_over_busy"] = ent.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / ent["SQ_BUSY_CYCLES"]
+            res["classes"][c] = ent
+        json.dump(res, open(os.path.join(out, f"{a.round}_mfma_util.json"), "w"), indent=1)
     print(sorted(os.listdir(out)))
 
 
