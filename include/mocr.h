@@ -55,7 +55,7 @@ enum {
                                            * key/value rows as OCP e4m3 (768 B per key instead of 1,536 B, static per-source
                                            * scales) and runs both products on fp8 MFMA, softmax in fp32.  NOT the parity
                                            * configuration: its accuracy is reported by tests/test_gpu_fp8_attention.py */
-    MOCR_FLAG_LATENT_ALWAYS = 1 << 6,     /* bf16: latent attention for every batch size (default: batches of <= 384 rows take the
+    MOCR_FLAG_LATENT_ALWAYS = 1 << 6,     /* bf16: latent attention for every batch size (default: batches of <= 256 rows take the
                                            * classic projected-K/V kernels, whose grid - one block per (row, head) - has half the
                                            * step latency there: 50 instead of 80 ms for 64 crops) */
     MOCR_FLAG_NO_SMALL_BATCH_PATH = 1 << 8, /* bf16: batches of <= 32 rows through the generic split-K projections + add/LayerNorm

@@ -181,7 +181,7 @@ struct mocr_engine : LaneCtx {
     float fold_ratio = 0.f;         // the worst ratio measured (0: not measured)
     long long n_slot_steps = 0;     // decode slots x steps enqueued so far (mocr_decode_slot_steps): what the steps cost, in rows
     long long n_compactions = 0;    // batches whose rows were compacted, counted per compaction (mocr_compaction_count)
-    int lat_tk = 17;                // bf16 latent attention kernel: 17 = latent_attnT_kernel (default); 16 / 32 = latent_attn_kernel on 16- / 32-key tiles
+    int lat_tk = 18;                // bf16 latent attention kernel: 18 = latent_attnT_kernel, three blocks per CU (default); 32 = latent_attn_kernel on 32-key tiles; experiments: 17, 16
     int Bc = 0;                     // rows the classic K/V buffers are sized for
     // Kernel regime of the batch being decoded: the row count the batch STARTED with (0: the launch's own row count).
     // Every choice a decode step makes by row count - attention path, GEMM tile, split-K slabs, fused query kernel,
@@ -753,6 +753,11 @@ void run_encoder(mocr_engine* e, const uint8_t* d_gray, int n) {
                      t1_env = env_int("MOCR_ENC_TILE_FC1", 0), t2_env = env_int("MOCR_ENC_TILE_FC2", 0);
     const int ETQ = tq_env ? tq_env : layer_tile(3 * D), ETO = to_env ? to_env : layer_tile(D), ET1 = t1_env ? t1_env : layer_tile(F);
     const int ET2 = t2_env ? t2_env : ETO;
+    // tile order of QKV / FC1: column groups whose weight slices stay in an XCD's 4 MiB L2 while the A row-panels stream through
+    // once per group.  128 x 128 tiles: groups of 9 / 12 N-tiles (r01).  Persistent 256 x 256 tiles: groups of 6 (r04: QKV 6 + 3,
+    // FC1 6 + 6: the whole 3.4 / 4.5 MiB weight does not fit beside the A panels, and without groups every XCD re-fetches it
+    // per round of row-panels - at batch 256 QKV 210 -> 200 us, FC1 337 -> 331 us, one box; tools/r04_groupn_ab.sh)
+    const int gq = ETQ >= 4096 ? 6 : 9, g1 = ET1 >= 4096 ? 6 : 12;
     gemm<T>(e, "gemm_patch_embed", e->Hb, P * P, w.wpe, w.bpe, e->X, D, nullptr, MPATCH, D, P * P, EPI_PATCH, ET, 1, 0,
             w.pos_enc, NP);
     const int impl = (e->cfg.flags & MOCR_FLAG_SIMPLE_ATTENTION) ? 0 : 1;
@@ -802,11 +807,11 @@ void run_encoder(mocr_engine* e, const uint8_t* d_gray, int n) {
             const EncLayerW& L = w.enc[l];
             LnFold use_q{e->ln_part, L.sqkv, nullptr}, use_1{e->ln_part, L.s1, nullptr}, emit{e->ln_part, nullptr, e->Xn};
             gemm<T>(e, "gemm_enc_qkv", e->Xn, D, L.wqkv_f, L.bqkv_f, e->QKV, 3 * D, nullptr, M, 3 * D, D, EPI_BIAS, ETQ, 1, 0, nullptr, 0, nullptr,
-                    9, nullptr, &use_q);
+                    gq, nullptr, &use_q);
             enc_attention<T>(e, e->QKV, e->CTX, n, impl);
             gemm<T>(e, "gemm_enc_oproj", e->CTX, D, L.wo, L.bo, e->X, D, e->X, M, D, D, EPI_BIAS_RESID, ETO, 1, 0, nullptr, 0, nullptr, 0,
                     nullptr, &emit);
-            gemm<T>(e, "gemm_enc_fc1", e->Xn, D, L.w1_f, L.b1_f, e->Hb, F, nullptr, M, F, D, EPI_BIAS_GELU, ET1, 1, 0, nullptr, 0, nullptr, 12,
+            gemm<T>(e, "gemm_enc_fc1", e->Xn, D, L.w1_f, L.b1_f, e->Hb, F, nullptr, M, F, D, EPI_BIAS_GELU, ET1, 1, 0, nullptr, 0, nullptr, g1,
                     nullptr, &use_1);
             gemm<T>(e, "gemm_enc_fc2", e->Hb, F, L.w2, L.b2, e->X, D, e->X, M, D, F, EPI_BIAS_RESID, ET2, 1, 0, nullptr, 0, nullptr, 0,
                     nullptr, &emit);
@@ -817,7 +822,7 @@ void run_encoder(mocr_engine* e, const uint8_t* d_gray, int n) {
     for (int l = 0; l < e->cfg.enc_layers; ++l) {
         const EncLayerW& L = w.enc[l];
         norm(L.ln1g, L.ln1b, e->Xn);
-        gemm<T>(e, "gemm_enc_qkv", e->Xn, D, L.wqkv, L.bqkv, e->QKV, 3 * D, nullptr, M, 3 * D, D, EPI_BIAS, ETQ, 1, 0, nullptr, 0, nullptr, 9);
+        gemm<T>(e, "gemm_enc_qkv", e->Xn, D, L.wqkv, L.bqkv, e->QKV, 3 * D, nullptr, M, 3 * D, D, EPI_BIAS, ETQ, 1, 0, nullptr, 0, nullptr, gq);
         enc_attention<T>(e, e->QKV, e->CTX, n, impl);
         if (split_o > 1) {
             gemm<T>(e, "gemm_enc_oproj", e->CTX, D, L.wo, nullptr, e->slabs, D, nullptr, M, D, D, EPI_SLAB, 64, split_o, (long long)M * D);
@@ -826,7 +831,7 @@ void run_encoder(mocr_engine* e, const uint8_t* d_gray, int n) {
             gemm<T>(e, "gemm_enc_oproj", e->CTX, D, L.wo, L.bo, e->X, D, e->X, M, D, D, EPI_BIAS_RESID, ETO, 1);
         }
         norm(L.ln2g, L.ln2b, e->Xn);
-        gemm<T>(e, "gemm_enc_fc1", e->Xn, D, L.w1, L.b1, e->Hb, F, nullptr, M, F, D, EPI_BIAS_GELU, ET1, 1, 0, nullptr, 0, nullptr, 12);
+        gemm<T>(e, "gemm_enc_fc1", e->Xn, D, L.w1, L.b1, e->Hb, F, nullptr, M, F, D, EPI_BIAS_GELU, ET1, 1, 0, nullptr, 0, nullptr, g1);
         if (split_2 > 1) {
             gemm<T>(e, "gemm_enc_fc2", e->Hb, F, L.w2, nullptr, e->slabs, D, nullptr, M, D, F, EPI_SLAB, 64, split_2, (long long)M * D);
             pend_bias = L.b2; pend_slabs = split_2;
@@ -975,16 +980,20 @@ void dec_attn(mocr_engine* e, int layer, int nslab, int n, const float* bias, in
     HIPCHECK(hipGetLastError());
 }
 
-// The bf16 latent attention launch (r04).  Default: latent_attnT_kernel - 16-key tiles on two persistent blocks per CU, the score
-// tile transposed so that the softmax's probabilities feed P.X from registers (two barriers per tile; kernels_latent_t.h).
-// MOCR_FLAG_LATENT_TILE32 = r03's kernel shape, the A/B partner: latent_attn_kernel on 32-key tiles, one block per CU (three
-// barriers per tile, kernels_latent.h).  Experiments build, MOCR_LAT_TK=16: that kernel on 16-key tiles, two blocks per CU
-// (the first half of r04; equal to the default within noise).
+// The bf16 latent attention launch (r04).  Default: latent_attnT_kernel<.., 2> - 16-key tiles, the score tile transposed so that
+// the softmax's probabilities feed P.X from registers (two barriers per tile; kernels_latent_t.h), THREE persistent blocks per
+// CU on two-slot rings (52 KiB of LDS, 152 registers).  MOCR_FLAG_LATENT_TILE32 = r03's kernel shape, the A/B partner:
+// latent_attn_kernel on 32-key tiles, one block per CU, three barriers per tile (kernels_latent.h).  Experiments build,
+// MOCR_LAT_TK = 17: the default kernel on three-slot rings, two blocks per CU (-2 % in the bench); 16: latent_attn_kernel on
+// 16-key tiles, two blocks per CU (the first half of r04; equal to 17 within noise).
 void launch_latent(mocr_engine* e, bool self, const LatentParams& p) {
     static const int lat_blocks = env_int("MOCR_LAT_BLOCKS", 0);      // persistent blocks (experiments; 0: one or two per CU by tile)
-    const int per_cu = e->lat_tk == 32 ? 1 : 2;
+    const int per_cu = e->lat_tk == 32 ? 1 : e->lat_tk == 18 ? 3 : 2;
     const int grid = std::min(p.rows, lat_blocks > 0 ? lat_blocks : per_cu * e->num_cus);
-    if (e->lat_tk == 17) {
+    if (e->lat_tk == 18) {          // the default: three blocks per CU on two-slot rings
+        if (self) hipLaunchKernelGGL((latent_attnT_kernel<true, 2>), dim3(grid), dim3(256), LAT3_LDS_OF(2), e->stream, p);
+        else hipLaunchKernelGGL((latent_attnT_kernel<false, 2>), dim3(grid), dim3(256), LAT3_LDS_OF(2), e->stream, p);
+    } else if (e->lat_tk == 17) {
         if (self) hipLaunchKernelGGL(latent_attnT_kernel<true>, dim3(grid), dim3(256), LAT3_LDS, e->stream, p);
         else hipLaunchKernelGGL(latent_attnT_kernel<false>, dim3(grid), dim3(256), LAT3_LDS, e->stream, p);
     } else if (e->lat_tk == 16) {
@@ -1332,6 +1341,8 @@ template <typename T> void init_kernel_attrs() {
     set_max_lds(latent_attn_kernel<false, 16>, LatCfg<16>::LDS);
     set_max_lds(latent_attnT_kernel<true>, LAT3_LDS);
     set_max_lds(latent_attnT_kernel<false>, LAT3_LDS);
+    set_max_lds((latent_attnT_kernel<true, 2>), LAT3_LDS_OF(2));
+    set_max_lds((latent_attnT_kernel<false, 2>), LAT3_LDS_OF(2));
     set_max_lds(latent_attn_fp8_kernel<true>, LAT8_LDS);
     set_max_lds(latent_attn_fp8_kernel<false>, LAT8_LDS);
 }
@@ -1894,12 +1905,14 @@ void allocate_lanes(mocr_engine* e) {
     compute_geometry(e);
     e->latent = e->cfg.dtype == MOCR_BF16 && !(e->cfg.flags & MOCR_FLAG_CLASSIC_ATTENTION);
     e->fp8attn = e->latent && (e->cfg.flags & MOCR_FLAG_FP8_ATTENTION);
-    e->lat_tk = (e->cfg.flags & MOCR_FLAG_LATENT_TILE32) ? 32 : env_int("MOCR_LAT_TK", 17);
+    e->lat_tk = (e->cfg.flags & MOCR_FLAG_LATENT_TILE32) ? 32 : env_int("MOCR_LAT_TK", 18);
     // Small batches of a latent engine take the classic kernels: the persistent latent kernel walks a sequence's key
     // tiles serially on ONE CU (~20 us per call whatever the batch), the classic one spreads a row over 12 blocks.
     // Measured (r01, 300 tokens): 8 rows 36 vs 73 ms, 64 rows 50 vs 80 ms, 256 rows 111 vs 116 ms; r02, both paths with
-    // non-temporal key loads: 320 rows 116 vs 126 ms, 384 rows 119 vs 129 ms, 448 / 512 rows (one graph shape) 159 vs 148 ms.
-    e->classic_rows = !e->latent ? 0 : (e->cfg.flags & MOCR_FLAG_LATENT_ALWAYS) ? 0 : std::min(env_int("MOCR_CLASSIC_ROWS", 384), e->cfg.max_batch);
+    // non-temporal key loads: 320 rows 116 vs 126 ms, 384 rows 119 vs 129 ms, 448 / 512 rows (one graph shape) 159 vs 148 ms;
+    // r04, latent on three blocks per CU (tools/r04_classic_rows_ab.sh, isolated batch, classic / latent, ms): 192 rows 76.8 /
+    // 90.2, 256 rows 90.3 / 96.1, 320 rows 113.3 / 107.7, 384 rows 116.1 / 110.5 - the switch moved from 384 to 256 rows.
+    e->classic_rows = !e->latent ? 0 : (e->cfg.flags & MOCR_FLAG_LATENT_ALWAYS) ? 0 : std::min(env_int("MOCR_CLASSIC_ROWS", 256), e->cfg.max_batch);
     e->Bc = e->latent ? e->classic_rows : e->Bp;
     e->smallm_rows = (e->cfg.dtype == MOCR_BF16 && e->D == 768 && e->F == 3072 && e->V % SM_NT == 0 && !(e->cfg.flags & MOCR_FLAG_NO_SMALL_BATCH_PATH))
                          ? std::min(SM_MAX_ROWS, env_int("MOCR_SMALLM_ROWS", SM_MAX_ROWS)) : 0;

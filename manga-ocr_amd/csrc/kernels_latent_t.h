@@ -23,7 +23,8 @@
 
 #define LAT3_TK 16
 #define LAT3_TILE_BYTES (LAT3_TK * LAT_D * 2)
-#define LAT3_LDS (LAT_NST * LAT3_TILE_BYTES + 4 * 16 * 16 * 4)      // ring + [4 waves][16 heads][16 keys] partial scores
+#define LAT3_LDS_OF(NST) ((NST) * LAT3_TILE_BYTES + 4 * 16 * 16 * 4)      // ring + [4 waves][16 heads][16 keys] partial scores
+#define LAT3_LDS LAT3_LDS_OF(3)
 
 // the four waves' partial scores of this lane's (head, 4 keys): 1 KiB apart
 __device__ __forceinline__ void lat3_read_partials(uint4* o, unsigned a) {
@@ -61,8 +62,11 @@ __device__ __forceinline__ void lat3_stage(const char* src, char* dst, unsigned 
         if (w + 3 * i < np) LAT_GLDS(src + ((src_base ^ (unsigned)(32 * i)) + (unsigned)(2 * i * LAT_D * 2)), dst + (w + 3 * i) * 1024);
 }
 
-template <bool SELF>
-__global__ __launch_bounds__(256, 2) void latent_attnT_kernel(LatentParams p) {
+// NST = ring slots: 3 (two tiles in flight, 76 KiB: two blocks per CU) or 2 (one tile in flight, 52 KiB: THREE blocks per CU -
+// the kernel needs 152 registers)
+template <bool SELF, int NST = 3>
+__global__ __launch_bounds__(256, NST == 2 ? 3 : 2) void latent_attnT_kernel(LatentParams p) {
+    static_assert(NST == 2 || NST == 3, "ring slots");
     constexpr int TK = LAT3_TK, TILE_BYTES = LAT3_TILE_BYTES, NPW = TK / 2, NP = 3 * NPW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const bf16_t* const P_qt = p.qt;
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void latent_attnT_kernel(LatentParams p) {
     // heads 0 .. 3 and what they compute is never used)
     const bf16_t* const q_lane = P_qt + (size_t)(l15 < P_heads ? l15 : l15 - P_heads) * LAT_D + 192 * wave + 8 * g;
     // partial scores: [wave][head][key 16] fp32; this lane's 16 bytes (head l15, keys 4 g .. 4 g + 3) of wave w at w * 1024 + sS_lane
-    const unsigned sS_lane = smem_base + LAT_NST * TILE_BYTES + (unsigned)(l15 * 64 + g * 16);
+    const unsigned sS_lane = smem_base + NST * TILE_BYTES + (unsigned)(l15 * 64 + g * 16);
 #define Q_PTR(row) (q_lane + (size_t)(row) * 16 * LAT_D)
 #define X_ROW(row) (P_x + (size_t)(P_rowmap ? lat_sload(P_rowmap + (row)) : (row)) * P_xstride)
 
@@ -142,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void latent_attnT_kernel(LatentParams p) {
                 issued += lat_pieces_of(np_, wave);                                                               \
             }                                                                                                     \
             if (islot == 0) mk0 = issued; else if (islot == 1) mk1 = issued; else mk2 = issued;                   \
-            islot = islot + 1 == LAT_NST ? 0 : islot + 1;                                                         \
+            islot = islot + 1 == NST ? 0 : islot + 1;                                                         \
             if (++it == cnt) ISSUE_ADVANCE_ROW();                                                                 \
         }                                                                                                         \
     } while (0)
@@ -167,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void latent_attnT_kernel(LatentParams p) {
         if (is_np > 0) {                                                                                          \
             if (wave < 3) issued += lat_pieces_of(is_np, wave);                                                   \
             if (islot == 0) mk0 = issued; else if (islot == 1) mk1 = issued; else mk2 = issued;                   \
-            islot = islot + 1 == LAT_NST ? 0 : islot + 1;                                                         \
+            islot = islot + 1 == NST ? 0 : islot + 1;                                                         \
             if (++it == cnt) ISSUE_ADVANCE_ROW();                                                                 \
         }                                                                                                         \
     } while (0)
@@ -175,12 +179,12 @@ __global__ __launch_bounds__(256, 2) void latent_attnT_kernel(LatentParams p) {
     // probability exactly 0) - or, the first time round, what the previous kernel left in LDS: cleared once
     if (np_last < NP) {
 #pragma unroll 4
-        for (int i = tid; i < LAT_NST * TILE_BYTES / 16; i += 256)
+        for (int i = tid; i < NST * TILE_BYTES / 16; i += 256)
             *reinterpret_cast<uint4*>(smem + (size_t)i * 16) = make_uint4(0, 0, 0, 0);
         __syncthreads();
     }
     ISSUE_NEXT();
-    ISSUE_NEXT();
+    if constexpr (NST == 3) ISSUE_NEXT();
     int slot = 0;
 
     while (cr < P_rows) {
@@ -208,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void latent_attnT_kernel(LatentParams p) {
             ISSUE_BEGIN();
             ISSUE_PART(0, 3);
             const unsigned xt_a = smem_base + (unsigned)(slot * TILE_BYTES);
-            slot = slot + 1 == LAT_NST ? 0 : slot + 1;
+            slot = slot + 1 == NST ? 0 : slot + 1;
 
             // ---- partial S^T[key][head] over this wave's 192 dims
             f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
@@ -228,7 +232,7 @@ __global__ __launch_bounds__(256, 2) void latent_attnT_kernel(LatentParams p) {
             }
             // the one exchange of the tile: 16 bytes per lane
             // (a plain store: the compiler pads the MFMA -> LDS-store hazard on sacc, which it does not do inside asm)
-            *reinterpret_cast<f32x4*>(smem + LAT_NST * TILE_BYTES + wave * 1024 + l15 * 64 + g * 16) = sacc;
+            *reinterpret_cast<f32x4*>(smem + NST * TILE_BYTES + wave * 1024 + l15 * 64 + g * 16) = sacc;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");

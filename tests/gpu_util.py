@@ -31,7 +31,7 @@ def weights(seed=0, eos_bias=0.0, vocab_bias_std=0.0, hostile=False):
 @functools.lru_cache(maxsize=None)
 def engine(dtype="fp32", seed=0, eos_bias=0.0, max_batch=8, flags=0, lanes=1, auto_path=False, vocab_bias_std=0.0, hostile=False):
     """bf16 engines of the tests run the latent attention at every batch size (flag 64) unless they ask for the classic
-    kernels (flag 8) or for the product's automatic choice (auto_path: classic up to 384 rows)."""
+    kernels (flag 8) or for the product's automatic choice (auto_path: classic up to 256 rows)."""
     from manga_ocr.engine import Engine
     if dtype == "bf16" and not auto_path and not (flags & 8):
         flags |= 64

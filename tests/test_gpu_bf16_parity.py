@@ -1,5 +1,5 @@
 """-m gpu: parity of the BENCHMARKED configuration - the bf16 engine on its automatic path (classic projected-K/V
-kernels up to 384 rows, latent attention above), through the C ABI, at BASELINE configs[1] / configs[2] row counts,
+kernels up to 256 rows, latent attention above), through the C ABI, at BASELINE configs[1] / configs[2] row counts,
 max_len 300 - against the reference arithmetic.
 
 What "bit-identical decoded token ids" can mean for a bf16 engine: greedy decoding is a chain of argmax decisions, and
@@ -67,10 +67,10 @@ def test_bf16_auto_path_free_running_ids_against_the_reference(gold, rows):
     # margin below the bf16 noise, so most 299-decision rows meet one
 
 
-@pytest.mark.parametrize("rows,path", [(320, "classic"), (448, "latent")])
+@pytest.mark.parametrize("rows,path", [(320, "latent"), (448, "latent")])
 def test_bf16_fat_batch_free_running_ids(gold, rows, path):
-    """Above configs[2]: 320 rows still take the classic kernels, 448 rows (> 384) the latent attention - the bench's merged
-    batches.  The rows are the 256 golden crops + repeats."""
+    """Above configs[2] (256 rows, the last row count on the classic kernels): 320 and 448 rows take the latent attention, like
+    the bench's merged batches.  The rows are the 256 golden crops + repeats."""
     eng = engine("bf16", max_batch=rows, auto_path=True)
     base = crops(777, 256)
     gray = np.concatenate([base, base[:rows - 256]])

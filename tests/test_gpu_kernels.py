@@ -63,22 +63,29 @@ def test_gemm_epilogues(dtype, tile, M, N, K, epi):
     assert err <= tol
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 768), (700, 2304, 768), (1000, 768, 3072), (256, 768, 256), (300, 512, 128)])
-@pytest.mark.parametrize("epi", [EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_BIAS_F32])
-@pytest.mark.parametrize("tile", [256, 512, 1024, 2048, 4096, 4097])
+def _big_tile_cases():
+    """(M, N, K, epi, tile) the big-tile kernels support: the A/B kernels of rounds 1-2 (tile codes 256 .. 2048) only in the
+    experiments build (MOCR_LIB=.../libmocr_hip_lab.so) - in the product run they are not collected at all."""
+    out = []
+    for tile in ([256, 512, 1024, 2048] if LAB else []) + [4096, 4097]:
+        for epi in (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_BIAS_F32):
+            for M, N, K in [(256, 256, 64), (512, 768, 768), (700, 2304, 768), (1000, 768, 3072), (256, 768, 256), (300, 512, 128)]:
+                if tile >= 512 and epi == EPI_BIAS_F32:      # the wide kernels have the encoder layers' epilogues only
+                    continue
+                if tile >= 2048 and K < 128:                  # the four-stage kernels (fragments requested across the K-tile barrier) need >= 4 K-tiles
+                    continue
+                if tile < 2048 and K == 128:                  # shape added for the four-stage kernels' shortest K loop
+                    continue
+                out.append((M, N, K, epi, tile))
+    return out
+
+
+@pytest.mark.parametrize("M,N,K,epi,tile", _big_tile_cases())
 def test_gemm_256x128_three_stage_ring(M, N, K, epi, tile):
     """The big-tile encoder kernels (bf16 only; 256 = 64-deep K-tiles, epilogue through LDS; 512 = the
     "wide" kernel: 32-deep K-tiles, two blocks per CU, epilogue from the registers): K from 1 to 96
     K-tiles exercises the ring's prologue, steady state (counted vmcnt) and drain; M not a multiple of
     256 exercises the row guard."""
-    if tile in (256, 512, 1024, 2048) and not LAB:
-        pytest.skip("A/B kernel of rounds 1-2: experiments build only (MOCR_LIB=.../libmocr_hip_lab.so)")
-    if tile >= 512 and epi == EPI_BIAS_F32:
-        pytest.skip("the wide kernel has the encoder layers' epilogues only")
-    if tile >= 2048 and K < 128:
-        pytest.skip("the four-stage wide kernels (tile codes 2048 / 4096: fragments requested across the K-tile barrier) need >= 4 K-tiles")
-    if tile < 2048 and K == 128:
-        pytest.skip("shape added for the four-stage kernel's shortest K loop")
     eng = engine("bf16")
     rs = np.random.RandomState(M + N + K + epi)
     Mp = (M + 255) // 256 * 256
@@ -367,14 +374,14 @@ def test_encoder_attention(dtype, impl, n):
     assert err <= tol
 
 
-@pytest.mark.parametrize("tile", [17, 32])
+@pytest.mark.parametrize("tile", [16, 32])
 @pytest.mark.parametrize("L,n", [(1, 5), (5, 5), (16, 5), (17, 5), (32, 5), (33, 5), (48, 5), (64, 5), (197, 5), (300, 5),
-                                 (20, 300), (40, 300), (70, 700), (197, 520), (20, 1100), (40, 1300)])
+                                 (20, 300), (40, 300), (70, 700), (197, 520), (20, 1100), (40, 1300), (20, 2000), (197, 1600)])
 def test_latent_attention(L, n, tile):
     """softmax(Qt X^T) X per head with the heads on the MFMA rows; keys streamed through the LDS ring
-    in tiles of 16 keys on two persistent blocks per CU (17: the default kernel, transposed score tile, kernels_latent_t.h)
-    or of 32 keys (MOCR_FLAG_LATENT_TILE32: r03's kernel shape); L = 1 .. 300 covers 1 to 19 tiles, partial last tiles and
-    the ring's drain; n > 512: persistent blocks take several sequences each (1, 2 and 3+ tile rows)."""
+    in tiles of 16 keys on three persistent blocks per CU (the default kernel: transposed score tile, two-slot rings,
+    kernels_latent_t.h) or of 32 keys (MOCR_FLAG_LATENT_TILE32: r03's kernel shape); L = 1 .. 300 covers 1 to 19 tiles, partial
+    last tiles and the ring's drain; n > 768: persistent blocks take several sequences each (1, 2 and 3+ tile rows)."""
     eng = engine("bf16", flags=1024 if tile == 32 else 0)
     rs = np.random.RandomState(L)
     H, D = 12, 768

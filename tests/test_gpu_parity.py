@@ -303,7 +303,7 @@ def test_two_lanes_in_flight_are_reproducible():
 
 
 def test_small_batches_take_the_classic_kernels_and_fat_ones_the_latent():
-    """The product engine chooses per batch: <= 384 rows classic (half the step latency at 64), more rows latent.  Same
+    """The product engine chooses per batch: <= 256 rows classic (half the step latency at 64), more rows latent.  Same
     kernels as the engines that are forced one way or the other, so the ids are identical to theirs."""
     auto = engine("bf16", max_batch=512, auto_path=True)
     classic = engine("bf16", max_batch=512, flags=8)
