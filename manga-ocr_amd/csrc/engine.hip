@@ -40,6 +40,7 @@
 #include "kernels_latent.h"
 #include "kernels_latent8.h"
 #include "kernels_latent_t.h"
+#include "kernels_latent_t8.h"
 #include "kernels_smallm.h"
 #include "preprocess.h"
 #include "prep_pipeline.h"
@@ -1006,10 +1007,26 @@ void launch_latent(mocr_engine* e, bool self, const LatentParams& p) {
     HIPCHECK(hipGetLastError());
 }
 
+// The fp8 latent attention launch: latent_attnT8_kernel (r04: transposed score tile, one 32-key tile per iteration, two blocks per
+// CU; kernels_latent_t8.h) or - MOCR_FLAG_LATENT_TILE32, the A/B partner - r02's latent_attn_fp8_kernel (two tiles per iteration
+// on a five-slot ring, one block per CU).
+void launch_latent8(mocr_engine* e, bool self, const Latent8Params& p) {
+    static const int lat_blocks = env_int("MOCR_LAT_BLOCKS", 0);
+    if (e->lat_tk == 32) {
+        const int grid = std::min(p.rows, lat_blocks > 0 ? lat_blocks : e->num_cus);
+        if (self) hipLaunchKernelGGL(latent_attn_fp8_kernel<true>, dim3(grid), dim3(256), LAT8_LDS, e->stream, p);
+        else hipLaunchKernelGGL(latent_attn_fp8_kernel<false>, dim3(grid), dim3(256), LAT8_LDS, e->stream, p);
+    } else {
+        const int grid = std::min(p.rows, lat_blocks > 0 ? lat_blocks : 2 * e->num_cus);
+        if (self) hipLaunchKernelGGL(latent_attnT8_kernel<true>, dim3(grid), dim3(256), LATT8_LDS, e->stream, p);
+        else hipLaunchKernelGGL(latent_attnT8_kernel<false>, dim3(grid), dim3(256), LATT8_LDS, e->stream, p);
+    }
+    HIPCHECK(hipGetLastError());
+}
+
 // Latent attention of n rows: Qt [n,16,768] x keys (self: cached layer-input rows; cross: encoder
 // output) -> Et [n,16,768].  bytes: the X rows streamed once (1,536 B per key).
 void latent_attn(mocr_engine* e, bool self, int layer, int n, int approx_len) {
-    static const int lat_blocks8 = env_int("MOCR_LAT_BLOCKS", 0) > 0 ? env_int("MOCR_LAT_BLOCKS", 0) : 256;
     if (e->fp8attn) {
         Latent8Params p{};
         p.qt = reinterpret_cast<const bf16_t*>(e->qt);
@@ -1030,9 +1047,7 @@ void latent_attn(mocr_engine* e, bool self, int layer, int n, int approx_len) {
         }
         ProfScope ps(e, self ? "lat8_attn_self" : "lat8_attn_cross", 4.0 * n * 16 * approx_len * e->D,
                      (double)n * approx_len * e->D + 2.0 * n * e->H * e->D * 2);     // e4m3 keys + Qt in + Et out (12 heads, bf16)
-        if (self) hipLaunchKernelGGL(latent_attn_fp8_kernel<true>, dim3(std::min(n, lat_blocks8)), dim3(256), LAT8_LDS, e->stream, p);
-        else hipLaunchKernelGGL(latent_attn_fp8_kernel<false>, dim3(std::min(n, lat_blocks8)), dim3(256), LAT8_LDS, e->stream, p);
-        HIPCHECK(hipGetLastError());
+        launch_latent8(e, self, p);
         return;
     }
     LatentParams p{};
@@ -1345,6 +1360,8 @@ template <typename T> void init_kernel_attrs() {
     set_max_lds((latent_attnT_kernel<false, 2>), LAT3_LDS_OF(2));
     set_max_lds(latent_attn_fp8_kernel<true>, LAT8_LDS);
     set_max_lds(latent_attn_fp8_kernel<false>, LAT8_LDS);
+    set_max_lds(latent_attnT8_kernel<true>, LATT8_LDS);
+    set_max_lds(latent_attnT8_kernel<false>, LATT8_LDS);
 }
 
 // `steps` consecutive greedy steps captured once and replayed: every per-step value (position,
@@ -2648,8 +2665,7 @@ int mocr_op_latent_attention_fp8(mocr_engine* e, const void* d_qt, const void* d
         p.out = reinterpret_cast<bf16_t*>(d_out); p.x_batch_stride = x_batch_stride_bytes; p.fixed_len = len; p.heads = e->H;
         p.rows = n; p.sx = sx;
         ProfScope ps(e, "op_latent8", 0, (double)n * len * 768);
-        hipLaunchKernelGGL(latent_attn_fp8_kernel<false>, dim3(std::min((int)n, env_int("MOCR_LAT_BLOCKS", 256))), dim3(256), LAT8_LDS, e->stream, p);
-        HIPCHECK(hipGetLastError());
+        launch_latent8(e, false, p);
         HIPCHECK(hipStreamSynchronize(e->stream));
     });
 }

@@ -63,12 +63,16 @@ def test_e4m3_quantiser_is_round_to_nearest_even_and_bit_exact():
     assert np.isfinite(got[keep]).all() and xin.size == x.size
 
 
-@pytest.mark.parametrize("L,n", [(1, 5), (5, 5), (32, 5), (33, 5), (64, 5), (160, 5), (197, 5), (300, 5), (20, 300), (197, 520), (290, 300)])
-def test_latent_attention_fp8_kernel(L, n):
-    """latent_attn_fp8_kernel against float64 attention on the SAME quantised operands (e4m3 keys, per-head e4m3 query;
-    exact probabilities): what is left is the e4m3 rounding of the probabilities (<= 6.25 % each, averaging out over
-    the keys) and the bf16 output.  Also reported: the error against the unquantised attention."""
-    eng = engine("bf16")
+@pytest.mark.parametrize("form", ["T", "r02"])
+@pytest.mark.parametrize("L,n", [(1, 5), (5, 5), (16, 5), (17, 5), (32, 5), (33, 5), (64, 5), (160, 5), (197, 5), (300, 5), (20, 300), (197, 520),
+                                 (290, 300), (40, 1300), (197, 1100)])
+def test_latent_attention_fp8_kernel(L, n, form):
+    """The fp8 latent attention - latent_attnT8_kernel (the default: transposed score tile, two blocks per CU) and r02's
+    latent_attn_fp8_kernel (MOCR_FLAG_LATENT_TILE32) - against float64 attention on the SAME quantised operands (e4m3 keys,
+    per-head e4m3 query; exact probabilities): what is left is the e4m3 rounding of the probabilities (<= 6.25 % each,
+    averaging out over the keys) and the bf16 output.  Also reported: the error against the unquantised attention.
+    n > 512: persistent blocks take several sequences each."""
+    eng = engine("bf16", flags=1024 if form == "r02" else 0)
     rs = np.random.RandomState(L + n)
     H, D = 12, 768
     stride = (L + 7) * D
@@ -103,7 +107,7 @@ def test_latent_attention_fp8_kernel(L, n):
     got = do[:, :H].float().cpu().numpy().astype(np.float64)
     scale = np.abs(ref_e).max()
     err_q, err_e = np.abs(got - ref_q).max(), np.abs(got - ref_e).max()
-    report(f"latent attention fp8 L={L} n={n}: max abs err vs quantisation-aware reference {err_q:.3e}, vs exact attention {err_e:.3e} "
+    report(f"latent attention fp8 ({form}) L={L} n={n}: max abs err vs quantisation-aware reference {err_q:.3e}, vs exact attention {err_e:.3e} "
            f"(|ref| max {scale:.2f})")
     assert np.isfinite(got).all()
     # vs the exact attention the bound is the e4m3 rounding of the keys themselves: half a unit in the 3-bit mantissa

@@ -29,7 +29,8 @@ import shutil
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 CLASSES = [  # (substring of the kernel symbol, bench.py's class name)
-    ("latent_attnT_kernel<true>", "lat_attn_self"), ("latent_attnT_kernel<false>", "lat_attn_cross"),      # r04 default
+    ("latent_attnT_kernel<true", "lat_attn_self"), ("latent_attnT_kernel<false", "lat_attn_cross"),      # r04 default
+    ("latent_attnT8_kernel<true", "lat8_attn_self"), ("latent_attnT8_kernel<false", "lat8_attn_cross"),
     ("latent_attn_kernel<true", "lat_attn_self"), ("latent_attn_kernel<false", "lat_attn_cross"),
     ("latent_attn_fp8_kernel<true>", "lat8_attn_self"), ("latent_attn_fp8_kernel<false>", "lat8_attn_cross"),
     ("dec_qqt_kernel", "dec_qqt"), ("enc_attn_mfma_kernel", "enc_attn_mfma"), ("enc_attn2_kernel", "enc_attn_mfma"),
@@ -141,13 +142,21 @@ def main():
                 e[1] += float(r["Counter_Value"])
         res = {"note": a.note, "rows": a.rows,
                "recipe": "rocprofv3 --pmc <SQ counters> (a pass of its own, no trace) of `python bench.py --steps 10 --warmup 0 --lanes 1 --only-timed`; "
-                         "per kernel class the mean per dispatch; mfma_busy_over_busy = SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES as the counters come",
+                         "per kernel class the mean per dispatch; mfma_util_of_peak_clock = SQ_VALU_MFMA_BUSY_CYCLES / (256 CUs x 4 SIMDs) / (launch duration x 2.4 GHz), "
+                         "the launch duration from the kernel trace of the same round (a bf16 16x16x32 MFMA keeps its SIMD's matrix pipe busy for 16 cycles: "
+                         "the ratio is the fraction of the 2.5 PFLOP/s dense peak the launch's MFMA instructions account for); "
+                         "mfma_busy_over_busy = SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES as the counters come",
                "classes": {}}
         for c, d in agg.items():
             ent = {k: v[1] / v[0] for k, v in d.items()}
             ent["dispatches"] = max(v[0] for v in d.values())
             if ent.get("SQ_BUSY_CYCLES"):
                 ent["mfma_busy_over_busy"] = ent.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / ent["SQ_BUSY_CYCLES"]
+            # matrix-pipe utilisation proper: busy cycles per SIMD (the counter sums the chip's 256 CUs x 4 SIMDs) over the cycles
+            # of the launch at the 2.4 GHz the 2.5 PF peak is priced at - duration from THIS round's kernel trace (--stats)
+            if c in classes and ent.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+                ent["avg_ns_from_trace"] = classes[c]["avg_ns"]
+                ent["mfma_util_of_peak_clock"] = ent["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (classes[c]["avg_ns"] * 2.4)
             res["classes"][c] = ent
         json.dump(res, open(os.path.join(out, f"{a.round}_mfma_util.json"), "w"), indent=1)
     print(sorted(os.listdir(out)))
