@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--events", action="store_true", help="also print the HIP-event breakdown of an eager pass")
     ap.add_argument("--encoder-only", action="store_true")
+    ap.add_argument("--dtype", default="bf16", help="bf16 or fp32 (the parity mode)")
     args = ap.parse_args()
 
     import torch
@@ -38,14 +39,14 @@ def main():
     from manga_ocr.weights import DEFAULT_SPEC, synthetic_weights
 
     spec = dataclasses.replace(DEFAULT_SPEC, max_len=args.max_len)
-    eng = Engine(synthetic_weights(0), spec, dtype="bf16", device=0, max_batch=args.batch, flags=args.flags, lanes=args.lanes)
+    eng = Engine(synthetic_weights(0), spec, dtype=args.dtype, device=0, max_batch=args.batch, flags=args.flags, lanes=args.lanes)
     B, L = args.batch, args.max_len
     gray = np.random.RandomState(1234).randint(0, 256, size=(B, 224, 224), dtype=np.uint8)
     d_gray = torch.from_numpy(gray).cuda()
     d_ids = torch.zeros((B, L), dtype=torch.int32, device="cuda")
     d_len = torch.zeros((B,), dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()
-    out = {"batch": B, "max_len": L, "flags": args.flags}
+    out = {"batch": B, "max_len": L, "flags": args.flags, "dtype": args.dtype}
     if args.encoder_only:
         eng.encode(d_gray, B)
         ts = []
