@@ -523,7 +523,7 @@ def main():
 
     # ---- strong-scaling probe: ONE batch of the rows a rank of the 8-GPU queue run gets, alone on this GPU
     probe = None
-    if extras and args.rows_per_rank_probe > 0:
+    if extras and not light and args.rows_per_rank_probe > 0:
         rows = args.rows_per_rank_probe
         nst = -(-rows // B)
         for rep in range(2):

@@ -992,11 +992,11 @@ void launch_latent(mocr_engine* e, bool self, const LatentParams& p) {
     const int per_cu = e->lat_tk == 32 ? 1 : e->lat_tk == 18 ? 3 : 2;
     const int grid = std::min(p.rows, lat_blocks > 0 ? lat_blocks : per_cu * e->num_cus);
     if (e->lat_tk == 18) {          // the default: three blocks per CU on two-slot rings
-        if (self) hipLaunchKernelGGL((latent_attnT_kernel<true, 2>), dim3(grid), dim3(256), LAT3_LDS_OF(2), e->stream, p);
-        else hipLaunchKernelGGL((latent_attnT_kernel<false, 2>), dim3(grid), dim3(256), LAT3_LDS_OF(2), e->stream, p);
+        if (self) hipLaunchKernelGGL((latent_attnT_kernel<true, 2>), dim3(grid), dim3(256), LATT_LDS_OF(2), e->stream, p);
+        else hipLaunchKernelGGL((latent_attnT_kernel<false, 2>), dim3(grid), dim3(256), LATT_LDS_OF(2), e->stream, p);
     } else if (e->lat_tk == 17) {
-        if (self) hipLaunchKernelGGL(latent_attnT_kernel<true>, dim3(grid), dim3(256), LAT3_LDS, e->stream, p);
-        else hipLaunchKernelGGL(latent_attnT_kernel<false>, dim3(grid), dim3(256), LAT3_LDS, e->stream, p);
+        if (self) hipLaunchKernelGGL(latent_attnT_kernel<true>, dim3(grid), dim3(256), LATT_LDS, e->stream, p);
+        else hipLaunchKernelGGL(latent_attnT_kernel<false>, dim3(grid), dim3(256), LATT_LDS, e->stream, p);
     } else if (e->lat_tk == 16) {
         if (self) hipLaunchKernelGGL((latent_attn_kernel<true, 16>), dim3(grid), dim3(256), LatCfg<16>::LDS, e->stream, p);
         else hipLaunchKernelGGL((latent_attn_kernel<false, 16>), dim3(grid), dim3(256), LatCfg<16>::LDS, e->stream, p);
@@ -1354,10 +1354,10 @@ template <typename T> void init_kernel_attrs() {
     set_max_lds(latent_attn_kernel<false, 32>, LatCfg<32>::LDS);
     set_max_lds(latent_attn_kernel<true, 16>, LatCfg<16>::LDS);
     set_max_lds(latent_attn_kernel<false, 16>, LatCfg<16>::LDS);
-    set_max_lds(latent_attnT_kernel<true>, LAT3_LDS);
-    set_max_lds(latent_attnT_kernel<false>, LAT3_LDS);
-    set_max_lds((latent_attnT_kernel<true, 2>), LAT3_LDS_OF(2));
-    set_max_lds((latent_attnT_kernel<false, 2>), LAT3_LDS_OF(2));
+    set_max_lds(latent_attnT_kernel<true>, LATT_LDS);
+    set_max_lds(latent_attnT_kernel<false>, LATT_LDS);
+    set_max_lds((latent_attnT_kernel<true, 2>), LATT_LDS_OF(2));
+    set_max_lds((latent_attnT_kernel<false, 2>), LATT_LDS_OF(2));
     set_max_lds(latent_attn_fp8_kernel<true>, LAT8_LDS);
     set_max_lds(latent_attn_fp8_kernel<false>, LAT8_LDS);
     set_max_lds(latent_attnT8_kernel<true>, LATT8_LDS);

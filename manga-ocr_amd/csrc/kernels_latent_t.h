@@ -17,17 +17,17 @@
 // barrier per tile: 13-15 % SLOWER than the split form at every length; removed.)
 // The DMA ring (three 24-KiB slots, two tiles in flight, requests spread over the iteration), the wave roles (waves 0-2
 // request, wave 3 stores), the counted waits, the trimmed last tile and the staged row end are latent_attn_kernel<.., 16>'s;
-// two blocks share a CU (76 KiB of LDS each).
+// by default THREE blocks share a CU (two-slot rings: 52 KiB of LDS each, 152 registers; NST = 3: 76 KiB, two blocks).
 #pragma once
 #include "kernels_latent.h"
 
-#define LAT3_TK 16
-#define LAT3_TILE_BYTES (LAT3_TK * LAT_D * 2)
-#define LAT3_LDS_OF(NST) ((NST) * LAT3_TILE_BYTES + 4 * 16 * 16 * 4)      // ring + [4 waves][16 heads][16 keys] partial scores
-#define LAT3_LDS LAT3_LDS_OF(3)
+#define LATT_TK 16
+#define LATT_TILE_BYTES (LATT_TK * LAT_D * 2)
+#define LATT_LDS_OF(NST) ((NST) * LATT_TILE_BYTES + 4 * 16 * 16 * 4)      // ring + [4 waves][16 heads][16 keys] partial scores
+#define LATT_LDS LATT_LDS_OF(3)
 
 // the four waves' partial scores of this lane's (head, 4 keys): 1 KiB apart
-__device__ __forceinline__ void lat3_read_partials(uint4* o, unsigned a) {
+__device__ __forceinline__ void latT_read_partials(uint4* o, unsigned a) {
     asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072\n\t"
                  "s_waitcnt lgkmcnt(0)"
                  : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]) : "v"(a) : "memory");
@@ -35,14 +35,14 @@ __device__ __forceinline__ void lat3_read_partials(uint4* o, unsigned a) {
 __device__ __forceinline__ void tr_read6(uint2* o, const unsigned* a);     // kernels_latent.h
 
 // max / sum over the four lanes l15, l15 + 16, l15 + 32, l15 + 48 (every lane ends with the total)
-__device__ __forceinline__ float lat3_xg_max(float v) {
+__device__ __forceinline__ float latT_xg_max(float v) {
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     v = fmaxf(__uint_as_float(r.x), __uint_as_float(r.y));
     r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     return fmaxf(__uint_as_float(r.x), __uint_as_float(r.y));
 }
-__device__ __forceinline__ float lat3_xg_sum(float v) {
+__device__ __forceinline__ float latT_xg_sum(float v) {
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     v = __uint_as_float(r.x) + __uint_as_float(r.y);
@@ -50,12 +50,12 @@ __device__ __forceinline__ float lat3_xg_sum(float v) {
     return __uint_as_float(r.x) + __uint_as_float(r.y);
 }
 // the value lane `src` holds
-__device__ __forceinline__ float lat3_from_lane(float v, int src) {
+__device__ __forceinline__ float latT_from_lane(float v, int src) {
     return __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(v)));
 }
 // request the pieces w + 3 i, i in [I0, I1), of one tile (pieces behind np hold no valid key: not requested)
 template <int I0, int I1>
-__device__ __forceinline__ void lat3_stage(const char* src, char* dst, unsigned src_base, int w, int np) {
+__device__ __forceinline__ void latT_stage(const char* src, char* dst, unsigned src_base, int w, int np) {
     asm volatile("" : "+v"(src_base));      // (the per-piece offsets are two VALU each: not to be computed once and kept - spilled - instead)
 #pragma unroll
     for (int i = I0; i < I1; ++i)
@@ -67,7 +67,7 @@ __device__ __forceinline__ void lat3_stage(const char* src, char* dst, unsigned 
 template <bool SELF, int NST = 3>
 __global__ __launch_bounds__(256, NST == 2 ? 3 : 2) void latent_attnT_kernel(LatentParams p) {
     static_assert(NST == 2 || NST == 3, "ring slots");
-    constexpr int TK = LAT3_TK, TILE_BYTES = LAT3_TILE_BYTES, NPW = TK / 2, NP = 3 * NPW;
+    constexpr int TK = LATT_TK, TILE_BYTES = LATT_TILE_BYTES, NPW = TK / 2, NP = 3 * NPW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const bf16_t* const P_qt = p.qt;
     const bf16_t* const P_x = p.x;
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256, NST == 2 ? 3 : 2) void latent_attnT_kernel(Lat
         if (ir < P_rows) {                                                                                        \
             const int np_ = it == cnt - 1 ? np_last : NP;                                                         \
             if (wave < 3) {                                                                                       \
-                lat3_stage<0, NPW>(reinterpret_cast<const char*>(ix) + (size_t)it * TILE_BYTES,                    \
+                latT_stage<0, NPW>(reinterpret_cast<const char*>(ix) + (size_t)it * TILE_BYTES,                    \
                                    smem + islot * TILE_BYTES, src_base, wave, np_);                               \
                 issued += lat_pieces_of(np_, wave);                                                               \
             }                                                                                                     \
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256, NST == 2 ? 3 : 2) void latent_attnT_kernel(Lat
     } while (0)
 #define ISSUE_PART(I0, I1)                                                                                        \
     do {                                                                                                          \
-        if (is_np > 0 && wave < 3) lat3_stage<I0, I1>(is_src, is_dst, src_base, wave, is_np);                     \
+        if (is_np > 0 && wave < 3) latT_stage<I0, I1>(is_src, is_dst, src_base, wave, is_np);                     \
     } while (0)
 #define ISSUE_END()                                                                                               \
     do {                                                                                                          \
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256, NST == 2 ? 3 : 2) void latent_attnT_kernel(Lat
             float al;
             {
                 uint4 ps[4];
-                lat3_read_partials(ps, sS_lane);
+                latT_read_partials(ps, sS_lane);
                 __builtin_amdgcn_sched_barrier(0);
                 float sv[4];
                 sv[0] = (__uint_as_float(ps[0].x) + __uint_as_float(ps[1].x)) + (__uint_as_float(ps[2].x) + __uint_as_float(ps[3].x));
@@ -253,12 +253,12 @@ __global__ __launch_bounds__(256, NST == 2 ? 3 : 2) void latent_attnT_kernel(Lat
                 for (int r = 0; r < 4; ++r)
                     if (t * TK + 4 * g + r >= L) sv[r] = -INFINITY;
                 float mx = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
-                mx = lat3_xg_max(mx);
+                mx = latT_xg_max(mx);
                 const float mn = mx > m_run ? mx : m_run;          // finite: every tile has a valid key
                 al = __expf(m_run - mn);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) pe[r] = __expf(sv[r] - mn);
-                l_run = l_run * al + lat3_xg_sum((pe[0] + pe[1]) + (pe[2] + pe[3]));
+                l_run = l_run * al + latT_xg_sum((pe[0] + pe[1]) + (pe[2] + pe[3]));
                 m_run = mn;
             }
             ISSUE_PART(6, NPW);
@@ -266,8 +266,8 @@ __global__ __launch_bounds__(256, NST == 2 ? 3 : 2) void latent_attnT_kernel(Lat
             // rescale the accumulators only when some head's running max moved (wave-uniform test); the factor of head
             // 4 g + r comes from the lane that owns that head
             if (__any(al != 1.0f)) {
-                const float a0 = lat3_from_lane(al, 4 * g), a1 = lat3_from_lane(al, 4 * g + 1), a2 = lat3_from_lane(al, 4 * g + 2),
-                            a3 = lat3_from_lane(al, 4 * g + 3);
+                const float a0 = latT_from_lane(al, 4 * g), a1 = latT_from_lane(al, 4 * g + 1), a2 = latT_from_lane(al, 4 * g + 2),
+                            a3 = latT_from_lane(al, 4 * g + 3);
 #pragma unroll
                 for (int dt = 0; dt < 12; ++dt) {
                     cacc[dt][0] *= a0; cacc[dt][1] *= a1; cacc[dt][2] *= a2; cacc[dt][3] *= a3;
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256, NST == 2 ? 3 : 2) void latent_attnT_kernel(Lat
         const int l15e = ln & 15, ge = ln >> 4;
         float inv[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) inv[r] = 1.0f / lat3_from_lane(l_run, 4 * ge + r);
+        for (int r = 0; r < 4; ++r) inv[r] = 1.0f / latT_from_lane(l_run, 4 * ge + r);
         static_assert(12 * LAT_OUT_HS <= TILE_BYTES, "the finished row is staged in one ring slot");
         char* const stg = smem + islot * TILE_BYTES;
         if (ge < 3) {                               // lane group 3 holds the padding heads 12..15

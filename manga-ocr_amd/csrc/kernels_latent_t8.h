@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256, 2) void latent_attnT8_kernel(Latent8Params p) 
             for (int s = 0; s < 6; ++s)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) am = fmaxf(am, fabsf((float)qb[s][j]));
-            am = lat3_xg_max(am);
+            am = latT_xg_max(am);
             if (g == 0) sAm[l15 * 4 + wave] = am;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void latent_attnT8_kernel(Latent8Params p) 
                     for (int r = 0; r < 4; ++r)
                         if (t * TK + 16 * j + 4 * g + r >= L) v[4 * j + r] = -INFINITY;
                 float mx = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7])));
-                mx = lat3_xg_max(mx);
+                mx = latT_xg_max(mx);
                 const float mn = mx > m_run ? mx : m_run;          // finite: every tile has a valid key
                 al = __expf(m_run - mn);
                 float pe[8];
@@ -261,15 +261,15 @@ __global__ __launch_bounds__(256, 2) void latent_attnT8_kernel(Latent8Params p) 
                             (__builtin_amdgcn_cvt_f32_fp8((int)lo, 2) + __builtin_amdgcn_cvt_f32_fp8((int)lo, 3))) +
                            ((__builtin_amdgcn_cvt_f32_fp8((int)hi, 0) + __builtin_amdgcn_cvt_f32_fp8((int)hi, 1)) +
                             (__builtin_amdgcn_cvt_f32_fp8((int)hi, 2) + __builtin_amdgcn_cvt_f32_fp8((int)hi, 3)));
-                l_run = l_run * al + lat3_xg_sum(pq) * (1.0f / LAT8_PSCALE);
+                l_run = l_run * al + latT_xg_sum(pq) * (1.0f / LAT8_PSCALE);
                 m_run = mn;
                 pa = ((unsigned long long)hi << 32) | lo;
             }
             ISSUE_PART8(6, NPW);
             ISSUE_END8();
             if (__any(al != 1.0f)) {
-                const float a0 = lat3_from_lane(al, 4 * g), a1 = lat3_from_lane(al, 4 * g + 1), a2 = lat3_from_lane(al, 4 * g + 2),
-                            a3 = lat3_from_lane(al, 4 * g + 3);
+                const float a0 = latT_from_lane(al, 4 * g), a1 = latT_from_lane(al, 4 * g + 1), a2 = latT_from_lane(al, 4 * g + 2),
+                            a3 = latT_from_lane(al, 4 * g + 3);
 #pragma unroll
                 for (int dt = 0; dt < 12; ++dt) {
                     cacc[dt][0] *= a0; cacc[dt][1] *= a1; cacc[dt][2] *= a2; cacc[dt][3] *= a3;
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void latent_attnT8_kernel(Latent8Params p) 
         {
             const float k = P_sx * (1.0f / LAT8_PSCALE);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) inv[r] = k / lat3_from_lane(l_run, 4 * ge + r);
+            for (int r = 0; r < 4; ++r) inv[r] = k / latT_from_lane(l_run, 4 * ge + r);
         }
         static_assert(12 * LAT_OUT_HS <= LATT8_SCRATCH, "the finished row is staged in the scratch");
         if (ge < 3) {
