@@ -661,6 +661,10 @@ void enc_attention(mocr_engine* e, const void* qkv, void* ctx, int n, int impl) 
         hipLaunchKernelGGL(enc_attn_mfma_kernel, dim3(n * H, ysplit), dim3(256), lds, e->stream,
                            reinterpret_cast<const bf16_t*>(qkv), reinterpret_cast<bf16_t*>(ctx), H, 3 * e->D, e->D, ablate_env);
 #endif
+    } else if (impl == 1 && sizeof(T) == 4) {          // r04: the parity mode on the f32-input matrix cores
+        ProfScope ps(e, "enc_attn_f32_mfma", flops, bytes);
+        hipLaunchKernelGGL(enc_attn_f32_kernel, dim3(n * H), dim3(256), EAF_LDS, e->stream, reinterpret_cast<const float*>(qkv),
+                           reinterpret_cast<float*>(ctx), H, 3 * e->D, e->D);
     } else {
         ProfScope ps(e, "enc_attn_simple", flops, bytes);
         constexpr int lds = (200 * 65 + 200 * 64 + 4 * 64 + 4 * 256) * 4;
@@ -1296,6 +1300,7 @@ template <typename T> void init_kernel_attrs() {
     set_max_lds(gemm_kernel<T, 64, 64, EPI_ARGMAX, 4>, 2 * l64);
     set_max_lds(enc_attn_simple_kernel<T>, (200 * 65 + 200 * 64 + 4 * 64 + 4 * 256) * 4);
     set_max_lds(enc_attn2_kernel, EA2_LDS);
+    set_max_lds(enc_attn_f32_kernel, EAF_LDS);
 #ifdef MOCR_EXPERIMENTS
     set_max_lds(enc_attn_mfma_kernel, ENC_SP * 128 + 64 * ENC_VT_LD * 2);
 #endif

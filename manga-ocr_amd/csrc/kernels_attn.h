@@ -82,6 +82,122 @@ __global__ __launch_bounds__(256) void enc_attn_simple_kernel(const T* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// enc_attn_f32_kernel (r04): the PARITY mode's encoder attention on the f32-input matrix cores.
+//   The VALU kernel above spends 3.0 ms per layer at batch 256 - 36 ms of the fp32 mode's 262 ms per 256-crop batch, more than
+//   any of its GEMMs.  v_mfma_f32_16x16x4_f32 is an exact fp32 fma chain (MI355X_MICROARCH.md: 32 cycles per SIMD, the fp32
+//   vector rate), so the products stay fp32-exact; only the order of the additions differs from the VALU kernel's (both
+//   are fp32 orderings of the same sums: the encoder rows stay within the 2e-4 the parity tests allow, measured ~1e-5).
+//   One block (4 waves) per (image, head); K and V as fp32 [208][68] in LDS (rows 197 .. 207 zero).  Per 16-query unit:
+//     S^T[key][q] = K . Q^T   13 key tiles x 16 MFMAs; the k index of an MFMA is a free bijection as long as both operands use
+//                             it: k-step s of lane group g stands for dim 16 g + s, so a lane's sixteen k values are 16
+//                             CONSECUTIVE floats of its key row (four ds_read_b128) / of its query row (four global loads);
+//     softmax                 lane (q = lane & 15, g) holds keys 16 kt + 4 g + r of every key tile: lane-local + two exchanges;
+//     O^T[d][q] = V^T . P^T   k-step (kt, r) of lane group g stands for key 16 kt + 4 g + r - where the lane's probability
+//                             register already is; A = V[key][16 dt + (lane & 15)]: one ds_read_b32 per MFMA.
+// ------------------------------------------------------------------------------------------------
+#ifndef ENC_S
+#define ENC_S 197
+#endif
+#define EAF_ROWS 208
+#define EAF_LD 68
+#define EAF_LDS (2 * EAF_ROWS * EAF_LD * 4)
+
+__global__ __launch_bounds__(256) void enc_attn_f32_kernel(const float* __restrict__ qkv, float* __restrict__ ctx, int H, int ld_qkv,
+                                                          int ld_ctx) {
+    constexpr int DH = 64, KT = 13;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* const sK = reinterpret_cast<float*>(smem);
+    float* const sV = sK + EAF_ROWS * EAF_LD;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int D = H * DH;
+    const float* base = qkv + (size_t)b * ENC_S * ld_qkv + h * DH;
+    for (int i = tid; i < EAF_ROWS * (DH / 4); i += 256) {
+        const int r = i >> 4, c = (i & 15) * 4;
+        float4 k4 = make_float4(0.f, 0.f, 0.f, 0.f), v4 = k4;
+        if (r < ENC_S) {
+            k4 = *reinterpret_cast<const float4*>(base + (size_t)r * ld_qkv + D + c);
+            v4 = *reinterpret_cast<const float4*>(base + (size_t)r * ld_qkv + 2 * D + c);
+        }
+        *reinterpret_cast<float4*>(sK + r * EAF_LD + c) = k4;
+        *reinterpret_cast<float4*>(sV + r * EAF_LD + c) = v4;
+    }
+    __syncthreads();
+    for (int unit = (wave + (int)blockIdx.x) & 3; unit < KT; unit += 4) {      // (the slot a wave takes rotates with the block)
+        const int q = unit * 16 + l15;
+        // this lane's query row, dims 16 g .. 16 g + 15 (k-steps 0 .. 15 of lane group g)
+        float qf[16];
+        {
+            const float* qrow = base + (size_t)(q < ENC_S ? q : ENC_S - 1) * ld_qkv + 16 * g;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 t = *reinterpret_cast<const float4*>(qrow + 4 * j);
+                qf[4 * j] = t.x; qf[4 * j + 1] = t.y; qf[4 * j + 2] = t.z; qf[4 * j + 3] = t.w;
+            }
+        }
+        // ---- S^T[key][q]: lane (q = l15, g) ends up with keys 16 kt + 4 g + r
+        f32x4 st[KT];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            const float* krow = sK + (16 * kt + l15) * EAF_LD + 16 * g;
+            float kf[16];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 t = *reinterpret_cast<const float4*>(krow + 4 * j);
+                kf[4 * j] = t.x; kf[4 * j + 1] = t.y; kf[4 * j + 2] = t.z; kf[4 * j + 3] = t.w;
+            }
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s], qf[s], acc, 0, 0, 0);
+            st[kt] = acc;
+        }
+        // ---- softmax over the 197 keys of this lane's query (52 here, the rest in the lanes l15 + 16, + 32, + 48)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (192 + 4 * g + r >= ENC_S) st[12][r] = -INFINITY;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kt][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = expf((st[kt][r] - mx) * 0.125f);      // exp(-inf) = 0 for the padded keys
+                st[kt][r] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        // ---- O^T[d][q] += V[key][d] P[key][q]: k-step (kt, r), lane group g <-> key 16 kt + 4 g + r
+        f32x4 oacc[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float* vrow = sV + (16 * kt + 4 * g + r) * EAF_LD + l15;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vrow[16 * dt], st[kt][r], oacc[dt], 0, 0, 0);
+            }
+        // lane (q = l15, g) holds d = 16 dt + 4 g + r of its query
+        if (q < ENC_S) {
+            const float inv = 1.0f / sum;
+            float* orow = ctx + ((size_t)b * ENC_S + q) * ld_ctx + h * DH + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                *reinterpret_cast<float4*>(orow + 16 * dt) = make_float4(oacc[dt][0] * inv, oacc[dt][1] * inv, oacc[dt][2] * inv, oacc[dt][3] * inv);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Encoder attention on MFMA (bf16).  One block (4 waves) per (image, head).
 //   LDS:  sK  [224 keys][64 d] bf16, 128-B rows, 16-B chunks XOR-swizzled like the GEMM tiles
 //         sVt [64 d][228 keys] bf16 (V transposed; 228 = conflict-free ds_read_b64 row stride)

@@ -344,10 +344,12 @@ def test_layernorm(dtype):
     assert err <= tol
 
 
-@pytest.mark.parametrize("dtype,impl,n", [("fp32", 0, 3), ("bf16", 0, 3), ("bf16", 1, 3), ("bf16", 1, 1), ("bf16", 1, 30), ("bf16", 1, 70)] +
+@pytest.mark.parametrize("dtype,impl,n", [("fp32", 0, 3), ("fp32", 1, 3), ("fp32", 1, 1), ("fp32", 1, 30), ("bf16", 0, 3), ("bf16", 1, 3), ("bf16", 1, 1),
+                                          ("bf16", 1, 30), ("bf16", 1, 70)] +
                          ([("bf16", 2, 3)] if LAB else []))
 def test_encoder_attention(dtype, impl, n):
-    """impl 0: the VALU kernel (fp32 parity mode); 1: the MFMA kernel of the bf16 engine (K / V by LDS-DMA, V read
+    """impl 0: the VALU kernel; 1: fp32 - the parity mode's kernel on the f32-input matrix cores (enc_attn_f32_kernel: exact fp32
+    products), bf16 - the MFMA kernel of the bf16 engine (K / V by LDS-DMA, V read
     column-wise with ds_read_b64_tr_b16) - 1 crop (four blocks share a head's 13 query units), 3 / 30 (two), 70 (one block
     per head, three blocks per CU); 2: the r02 kernel (experiments build)."""
     eng = engine(dtype)
@@ -368,7 +370,7 @@ def test_encoder_attention(dtype, impl, n):
     eng.op_enc_attention(dQ, dC, n, impl)
     got = dC.float().cpu().numpy().astype(np.float64)
     err = np.abs(got - ref).max()
-    tol = 5e-6 if dtype == "fp32" else 2e-2
+    tol = 1e-5 if dtype == "fp32" else 2e-2      # fp32: 2e-6 of the largest value - a few hundred fp32 additions per output, in either order
     report(f"enc attention {dtype} impl{impl}: max abs err {err:.3e} (|ref| max {np.abs(ref).max():.2f})")
     assert np.isfinite(got).all()
     assert err <= tol
