@@ -154,6 +154,8 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-parity-leg", action="store_true", help="skip the fp32 parity-mode / bf16 id-match record (tests/golden crops)")
     ap.add_argument("--no-mixed", action="store_true", help="skip the mixed-lengths record (EOS-biased weights, row compaction on / off)")
+    ap.add_argument("--mixed-steps", type=int, default=20, help="steps of B crops the mixed-lengths leg queues (a deeper queue lets a third lane start the next batch while two tail off)")
+    ap.add_argument("--only-mixed", action="store_true", help="the mixed-lengths leg only (experiments: lanes / queue depth)")
     ap.add_argument("--rows-per-rank-probe", type=int, default=1250,
                     help="time ONE batch of this many rows (10000 / 8 = 1250: what a rank of the 8-GPU strong-scaling run decodes) and "
                          "report the strong-scaling bound it implies")
@@ -280,10 +282,13 @@ def main():
     steps_timed = max(steps_local, 1) if strong else args.steps
 
     extras = rank == 0 and not args.only_timed
+    if args.only_mixed:
+        args.no_profile = args.no_config4 = args.no_parity_leg = args.no_cpu_baseline = True
+        args.rows_per_rank_probe = 0
     light = world > 1          # N > 1: the other ranks wait for rank 0 at the final barrier - keep its extra legs short
     # ---- T = 32 regime (max_len = 33: a typical speech bubble), same queue, same engine
     t32 = None
-    if extras and not strong and not light and L > 33:
+    if extras and not strong and not light and L > 33 and not args.only_mixed:
         eng.set_generate_max_length(33)
         run(args.steps)
         t0 = time.perf_counter()
@@ -295,7 +300,7 @@ def main():
 
     # ---- one isolated step (B crops submitted alone, nothing to merge with): the latency a single caller sees
     isolated = {}
-    if extras and not light:
+    if extras and not light and not args.only_mixed:
         more = {int(v) for v in os.environ.get("MOCR_BENCH_ISOLATED", "").split(",") if v}      # extra sizes (experiments)
         for b in sorted({8, 64, 256, B} | more):
             if b > B:
@@ -466,7 +471,8 @@ def main():
     if extras and not strong and not light and not args.no_mixed and args.dtype == "bf16" and L == 300:
         wm = synthetic_weights(1, eos_bias=1.1)
         mb = min(args.max_batch, 2560)
-        nq = min(args.steps, 20) * B
+        K = max(K, 1)
+        nq = args.mixed_steps * B
         gm = np.random.RandomState(4322).randint(0, 256, size=(nq, 224, 224), dtype=np.uint8)
         dgm = torch.from_numpy(gm).cuda()
         oi = torch.zeros((nq, L), dtype=torch.int32, device="cuda")
