@@ -154,7 +154,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-parity-leg", action="store_true", help="skip the fp32 parity-mode / bf16 id-match record (tests/golden crops)")
     ap.add_argument("--no-mixed", action="store_true", help="skip the mixed-lengths record (EOS-biased weights, row compaction on / off)")
-    ap.add_argument("--mixed-steps", type=int, default=20, help="steps of B crops the mixed-lengths leg queues (a deeper queue lets a third lane start the next batch while two tail off)")
+    ap.add_argument("--mixed-steps", type=int, default=60, help="steps of B crops the mixed-lengths leg queues (a deeper queue lets a third lane start the next batch while two tail off)")
     ap.add_argument("--only-mixed", action="store_true", help="the mixed-lengths leg only (experiments: lanes / queue depth)")
     ap.add_argument("--rows-per-rank-probe", type=int, default=1250,
                     help="time ONE batch of this many rows (10000 / 8 = 1250: what a rank of the 8-GPU strong-scaling run decodes) and "
@@ -466,7 +466,8 @@ def main():
     # uses the EOS-biased synthetic weights of tests/golden/early_eos_seed1.npz (seed 1, eos_bias 1.1): rows end after ~17 .. 300
     # tokens.  Same queue shape as the headline (steps of B crops merged by the engine), with the engine's row compaction and -
     # second engine - without it (MOCR_FLAG_NO_COMPACTION); `mean_length_time_s` is the headline engine decoding the same
-    # number of crops with EVERY row at the mixed queue's mean length (what an ideal scheduler's decode work amounts to).
+    # number of crops with EVERY row at the mixed queue's mean length (what an ideal scheduler's decode work amounts to).  The
+    # queue is deep (--mixed-steps 60 = 15,360 crops): lanes take 2560 rows each as they fall idle.
     mixed = None
     if extras and not strong and not light and not args.no_mixed and args.dtype == "bf16" and L == 300:
         wm = synthetic_weights(1, eos_bias=1.1)
@@ -493,8 +494,10 @@ def main():
             return best, slots, ol.cpu().numpy().copy(), oi.cpu().numpy().copy()
 
         res = {}
-        for name, fl in (("compacted", 0), ("uncompacted", 2048)):
-            em = Engine(wm, spec, dtype=args.dtype, device=local, max_batch=mb, lanes=args.lanes, flags=fl | args.engine_flags)
+        # (a third lane starts the next batch of a deep queue while two tail off on a few hundred slots: the cheap form of
+        # refilling finished slots from the queue)
+        for name, fl, nl in (("compacted", 0, args.lanes), ("uncompacted", 2048, args.lanes), ("compacted_3_lanes", 0, max(3, args.lanes))):
+            em = Engine(wm, spec, dtype=args.dtype, device=local, max_batch=mb, lanes=nl, flags=fl | args.engine_flags)
             dtm, slots, lens_m, ids_m = run_mixed(em)
             ncomp = em.compaction_count()
             em.close()
@@ -522,6 +525,9 @@ def main():
                  "useful_token_fraction": tokens / max(res["compacted"][1], 1),
                  "uncompacted": {"crops_per_s": nq / res["uncompacted"][0], "seconds": res["uncompacted"][0],
                                  "useful_token_fraction": tokens / max(res["uncompacted"][1], 1)},
+                 "three_lanes": {"crops_per_s": nq / res["compacted_3_lanes"][0], "seconds": res["compacted_3_lanes"][0],
+                                 "time_over_mean_length_time": res["compacted_3_lanes"][0] / tmean,
+                                 "ids_identical": bool((res["compacted_3_lanes"][3] == res["uncompacted"][3]).all())},
                  "ids_identical_to_uncompacted": bool((res["compacted"][3] == res["uncompacted"][3]).all()),
                  "mean_length_time_s": tmean, "mean_length_tokens": ml,
                  "time_over_mean_length_time": res["compacted"][0] / tmean}
