@@ -1434,7 +1434,7 @@ static int graph_rows(int n, int max_batch) {
     else if (n <= 64) q = 8;
     else if (n <= 256) q = 32;
     else if (n <= 1024) q = 128;
-    else q = 512;
+    else q = 256;       // (r04: 512 until rows were compacted - a batch now passes through these row counts on its way down)
     return std::min(round_up(n, q), max_batch);
 }
 
