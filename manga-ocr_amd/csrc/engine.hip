@@ -1082,7 +1082,9 @@ void latent_block(mocr_engine* e, bool self, int layer, int n, int t, const void
     const int D = e->D;
     // fat batches: q and Qt in one launch (kernels_qqt.h), 37 us instead of 16 + 31 at 4096 rows; bit-identical to the
     // two-launch path.  MOCR_DEC_QQT_ROWS = rows from which it is used (0 = never)
-    static const int qqt_rows = env_int("MOCR_DEC_QQT_ROWS", 1024);
+    // (r04, tools/r04_qqt_rows_ab.sh, isolated batch, two launches / fused: 512 rows 136.2 / 134.9 ms, 768 rows 165.4 / 163.5, below
+    // 512 rows the two launches stay ahead: the switch moved from 1024 to 512 rows)
+    static const int qqt_rows = env_int("MOCR_DEC_QQT_ROWS", 512);
     if (qqt_rows > 0 && e->rrows(n) >= qqt_rows && D == 768 && e->H == 12 && !(e->cfg.flags & MOCR_FLAG_NO_FUSED_QQT)) {
         QqtParams q{};
         q.x = reinterpret_cast<const bf16_t*>(xin); q.wq = reinterpret_cast<const bf16_t*>(wq); q.bq = bq;
