@@ -10,9 +10,11 @@ weights EOS never fires, so every row decodes the full T = max_len - 1 = 299 ste
 N > 1: one process per GPU (torch.distributed / RCCL), launched by torch.distributed.run.
   * weak scaling (default): every rank gets its own B crops per step, no data-path collective; the decoded ids are
     all-gathered ONCE per timed job (the only exchange step, SURVEY.md §8e);
-  * --queue Q (BASELINE configs[3], Q = 10000): strong scaling - ONE queue of Q crops is split into contiguous
-    shards, every rank decodes its shard in batches of B, then ONE all-gather of the [n_local_max, max_len + 1]
-    int32 rows; value = Q / max-over-ranks wall time.
+  * --queue Q (BASELINE configs[3], Q = 10000): strong scaling - ONE queue of Q crops is DEALT as the product's multi-GPU
+    dispatcher deals it (manga_ocr.multi.deal_sizes: whole rounds of equal chunks of at most lanes x max_batch rows - 8 chunks
+    of 1250 for 10,000 crops on 8 GPUs): the ranks pull chunk numbers from one shared counter (the reference's workers POP
+    jobs, src/ui/main_window.py:4329-4335), decode them in batches of B, then ONE exchange of the [Q, max_len + 1] int32 rows
+    (an all-reduce of a block every row of which exactly one rank wrote); value = Q / max-over-ranks wall time.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--max-len L] [--queue Q] [--dtype bf16|fp32]
 
@@ -144,7 +146,9 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--lanes", type=int, default=2, help="internal batches the engine keeps in flight (streams + workspaces)")
     ap.add_argument("--max-batch", type=int, default=8192, help="rows of one internal engine batch: submitted steps are merged up to this")
-    ap.add_argument("--queue", type=int, default=0, help="strong-scaling mode: ONE queue of this many crops sharded over the ranks (configs[3]: 10000)")
+    ap.add_argument("--queue", type=int, default=0, help="strong-scaling mode: ONE queue of this many crops dealt to the ranks in chunks (configs[3]: 10000)")
+    ap.add_argument("--deal", default="equal", choices=("equal", "guided"),
+                    help="--queue: the chunking policy of manga_ocr.multi.deal_sizes the ranks pull from (the product's default: equal)")
     ap.add_argument("--cpu-sample", type=int, default=48, help="crops per regime the CPU baseline (oracle) decodes: ~15-20 s of CPU work in all")
     ap.add_argument("--fp8-attention", action="store_true",
                     help="opt-in mode of BASELINE configs[4]: e4m3 key/value rows + fp8 MFMA in the decode attention (not the parity configuration)")
@@ -171,7 +175,6 @@ def main():
 
     import torch
     from manga_ocr.engine import Engine
-    from manga_ocr.shard import shard_bounds
     from manga_ocr.weights import DEFAULT_SPEC, synthetic_weights
 
     rank = int(os.environ.get("RANK", "0"))
@@ -210,21 +213,28 @@ def main():
     dtype_label = args.dtype + ("+fp8attn" if args.fp8_attention else "")
     B, L = args.batch, args.max_len
     strong = args.queue > 0
+    chunks, store, deal_seq, dealt = [], None, [0], []
     if strong:
-        lo, hi = shard_bounds(args.queue, world, rank)
-        n_local, n_max = hi - lo, -(-args.queue // world)
-        steps_local = -(-n_local // B)
+        # the queue is DEALT, as the product's multi-GPU dispatcher deals it (manga_ocr/multi.py: deal_sizes - whole rounds of
+        # equal chunks of at most lanes x max_batch rows): the SPMD ranks pull chunk numbers from one shared counter (the
+        # process group's store: an atomic add on rank 0's TCP store), decode what they pulled, and exchange once at the end
+        from manga_ocr.multi import deal_sizes
+        chunks = deal_sizes(args.queue, world, args.max_batch * args.lanes, policy=args.deal)
+        steps_local = -(-max(b - a for a, b in chunks) // B)
+        if use_dist:
+            from torch.distributed import distributed_c10d
+            store = distributed_c10d._get_default_store()
     else:
-        n_local = n_max = steps_local = 0
-    # this rank's crops: global crop ids [rank*B, (rank+1)*B) of every step (weak), or its shard of the queue (strong)
-    gray = np.random.RandomState(1234 + rank).randint(0, 256, size=(B, 224, 224), dtype=np.uint8)
+        steps_local = 0
+    # this rank's crops: global crop ids [rank*B, (rank+1)*B) of every step (weak); strong: every chunk replays the SAME B
+    # crops from its first row on, whoever pulls it
+    gray = np.random.RandomState(1234 + (0 if strong else rank)).randint(0, 256, size=(B, 224, 224), dtype=np.uint8)
     d_gray = torch.from_numpy(gray).to(dev)
     K = max(args.steps, args.warmup, steps_local, 1)
     d_ids = torch.zeros((K, B, L), dtype=torch.int32, device=dev)      # one output block per step
     d_len = torch.zeros((K, B), dtype=torch.int32, device=dev)
     if strong:
-        d_rows = torch.zeros((n_max, L + 1), dtype=torch.int32, device=dev)
-        d_all = torch.zeros((world * n_max, L + 1), dtype=torch.int32, device=dev) if use_dist else None
+        d_all = torch.zeros((args.queue, L + 1), dtype=torch.int32, device=dev)      # every row of the queue: ids + length
     else:
         d_all = torch.zeros((world * K, B, L), dtype=torch.int32, device=dev) if use_dist else None
     torch.cuda.synchronize()
@@ -233,17 +243,30 @@ def main():
         # submit every step's batch (the engine merges them into fat internal batches and overlaps those on its
         # lanes), run them to completion, then the job's one exchange: all-gather of the decoded ids (RCCL over xGMI)
         if strong:
-            left = n_local
-            for i in range(steps_local):
-                eng.recognize_device(d_gray, min(B, left), d_ids[i], d_len[i])
-                left -= B
-            eng.synchronize()
-            if n_local:
-                flat = d_ids[:steps_local].reshape(-1, L)[:n_local]
-                d_rows[:n_local, :L] = flat
-                d_rows[:n_local, L] = d_len[:steps_local].reshape(-1)[:n_local]
+            key = f"mocr_bench_deal_{deal_seq[0]}"          # one counter per pass (every rank makes the same passes in the same order)
+            deal_seq[0] += 1
+            del dealt[:]
+            d_all.zero_()
+            nxt = 0
+            while True:
+                if store is not None:
+                    idx = store.add(key, 1) - 1
+                else:
+                    idx, nxt = nxt, nxt + 1
+                if idx >= len(chunks):
+                    break
+                lo, hi = chunks[idx]
+                n, left = hi - lo, hi - lo
+                ns = -(-n // B)
+                for i in range(ns):
+                    eng.recognize_device(d_gray, min(B, left), d_ids[i], d_len[i])
+                    left -= B
+                eng.synchronize()
+                d_all[lo:hi, :L] = d_ids[:ns].reshape(-1, L)[:n]
+                d_all[lo:hi, L] = d_len[:ns].reshape(-1)[:n]
+                dealt.append(idx)
             if use_dist:
-                dist.all_gather_into_tensor(d_all, d_rows)
+                dist.all_reduce(d_all)        # a row is written by exactly one rank (zeros elsewhere): the sum IS the gather
             return
         for i in range(nsteps):
             eng.recognize_device(d_gray, B, d_ids[i], d_len[i])
@@ -277,6 +300,12 @@ def main():
     if strong or args.warmup != args.steps:
         run(args.steps)
     dt = timed(args.steps)
+    per_rank_chunks = [len(dealt)]
+    if strong and use_dist:
+        cnt = torch.tensor([len(dealt)], dtype=torch.int64, device=dev)
+        allc = torch.zeros(world, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(allc, cnt)
+        per_rank_chunks = [int(v) for v in allc.tolist()]
     crops_timed = args.queue if strong else world * B * args.steps
     value = crops_timed / dt
     steps_timed = max(steps_local, 1) if strong else args.steps
@@ -565,8 +594,10 @@ def main():
         cfg_name = {256: "BASELINE configs[2]", 64: "BASELINE configs[1]"}.get(B, "custom batch")
         if strong:
             cfg_name = "BASELINE configs[3]" if args.queue == 10000 else "sharded queue"
-            workload = (f"{cfg_name}: ONE queue of {args.queue} synthetic 224x224 crops sharded contiguously over {world} GPU(s), decoded in "
-                        f"batches of {B}, ONE all-gather of int32 [n_local_max, {L + 1}] rows")
+            sizes = sorted({b - a for a, b in chunks}, reverse=True)
+            workload = (f"{cfg_name}: ONE queue of {args.queue} synthetic 224x224 crops dealt to {world} GPU(s) in {len(chunks)} chunk(s) of "
+                        f"{'/'.join(str(v) for v in sizes[:4])} rows (manga_ocr.multi.deal_sizes, policy {args.deal}: the product dispatcher's "
+                        f"chunking; ranks pull chunk numbers from a shared counter), decoded in batches of {B}, ONE exchange of int32 [{args.queue}, {L + 1}] rows")
         else:
             workload = (f"{cfg_name}: batch={B} synthetic 224x224 crops per GPU per step (stand-ins for real manga crops: no dataset or "
                         f"checkpoint offline; same shapes, FLOPs and bytes)")
@@ -586,6 +617,9 @@ def main():
             "parity": parity, "mixed_lengths": mixed, "strong_scaling_probe": probe,
             "roofline": roof, "cpu_baseline": cpu, "kernels": kernels[:24],
         }
+        if strong:
+            out["dealing"] = {"policy": args.deal, "chunks": len(chunks), "chunk_rows": [b - a for a, b in chunks][:32],
+                              "chunks_pulled_per_rank": per_rank_chunks, "counter": "c10d store add" if store is not None else "local (one rank)"}
         if fake:      # the rehearsal's evidence that every rank's rows arrived, in rank order
             out["data"] = "synthetic (FAKE ENGINE: a CPU rehearsal of the collective path, not a measurement)"
             out["gathered_checksum"] = int(d_all.to(torch.int64).sum().item()) if d_all is not None else None

@@ -212,14 +212,40 @@ def _worker_main(rank: int, world: int, device: int, port: int, backend: str, fa
 
 
 # ------------------------------------------------------------------------------------------------ parent
-def deal_sizes(n: int, world: int, max_chunk: int, min_chunk: int = _MIN_CHUNK) -> List[Tuple[int, int]]:
-    """The queue [0, n) cut into the chunks the parent deals, in order: guided self-scheduling - a chunk is the rows
-    left divided by twice the workers, at most what one child's engine decodes at once (`max_chunk`), at least
-    `min_chunk` - fat chunks first (throughput is bought with fat batches), small ones last (the children finish
-    together whatever the rows cost)."""
+_DEAL = os.environ.get("MANGA_OCR_DEAL", "equal")                     # "equal" | "guided"
+
+
+def deal_sizes(n: int, world: int, max_chunk: int, min_chunk: int = _MIN_CHUNK, policy: Optional[str] = None) -> List[Tuple[int, int]]:
+    """The queue [0, n) cut into the chunks that are dealt, in order (the parent of `MultiGpuEngine` deals them to whichever
+    child has room; `bench.py --queue` lets its SPMD ranks pull them from a shared counter).
+
+    "equal" (default): whole rounds of EQUAL fat chunks - ceil(n / (world x max_chunk)) rounds of `world` chunks, each at
+    most what one child's engine decodes at once (`max_chunk`).  A decode's cost is mostly its step count, not its rows
+    (one GPU, 300 steps: 64 rows 50 ms, 256 rows 91 ms, 1250 rows 231 ms, 2560 rows 305 ms), so on equal workers the
+    fattest chunks win: 10,000 crops on 8 children are 8 chunks of 1250 - the static shards, dealt; a child that is
+    late, slow or dead still only costs what it holds (re-dealt on failure).
+    "guided" (r03's schedule; MANGA_OCR_DEAL=guided): a chunk is the rows left divided by twice the workers, at most
+    `max_chunk`, at least `min_chunk` - fat chunks first, small ones last: children of UNEQUAL speed finish together, at
+    the price of a tail of small decodes (625, 586, 549 ... 64 rows for the queue above: ~3 x the time on a healthy node)."""
+    policy = policy or _DEAL
+    if policy not in ("equal", "guided"):
+        raise ValueError(f"MANGA_OCR_DEAL / policy must be 'equal' or 'guided', not {policy!r}")
+    world = max(world, 1)
     out, lo = [], 0
+    if policy == "equal":
+        if n <= 0:
+            return out
+        rounds = -(-n // (world * max_chunk))
+        k = min(rounds * world, -(-n // max(1, min(min_chunk, max_chunk))))      # never thinner than min_chunk (but cover n)
+        k = max(k, -(-n // max_chunk))
+        base, extra = divmod(n, k)
+        for i in range(k):
+            hi = lo + base + (1 if i < extra else 0)
+            out.append((lo, hi))
+            lo = hi
+        return out
     while lo < n:
-        c = max(min_chunk, min(max_chunk, -(-(n - lo) // (2 * max(world, 1)))))
+        c = max(min_chunk, min(max_chunk, -(-(n - lo) // (2 * world))))
         hi = min(n, lo + c)
         out.append((lo, hi))
         lo = hi
@@ -356,23 +382,26 @@ class MultiGpuEngine:
                     pass
 
             def deal():
-                for r in list(out):
-                    while len(out[r]) < _DEPTH and queue:
-                        # the first chunk this child is allowed to take (a re-dealt chunk avoids the child it failed on,
-                        # unless that is the only one left)
-                        pick = next((i for i, c in enumerate(queue) if c[3] != r or len(out) == 1), None)
-                        if pick is None:
-                            break
-                        c = queue[pick]
-                        del queue[pick]
-                        try:
-                            self._conns[r].send(("chunk", jid, c[0], c[1]))
-                        except (OSError, BrokenPipeError, ValueError):
-                            queue.appendleft(c)
-                            lose(r, "pipe closed")
-                            break
-                        out[r].append(c)
-                        stats["chunks"][r] += 1
+                # breadth first: every child gets its first chunk before anyone gets a second (eight equal chunks on eight
+                # children are one each)
+                for depth in range(1, _DEPTH + 1):
+                    for r in list(out):
+                        while r in out and len(out[r]) < depth and queue:
+                            # the first chunk this child is allowed to take (a re-dealt chunk avoids the child it failed
+                            # on, unless that is the only one left)
+                            pick = next((i for i, c in enumerate(queue) if c[3] != r or len(out) == 1), None)
+                            if pick is None:
+                                break
+                            c = queue[pick]
+                            del queue[pick]
+                            try:
+                                self._conns[r].send(("chunk", jid, c[0], c[1]))
+                            except (OSError, BrokenPipeError, ValueError):
+                                queue.appendleft(c)
+                                lose(r, "pipe closed")
+                                break
+                            out[r].append(c)
+                            stats["chunks"][r] += 1
 
             deal()
             while any(out.values()) or queue:

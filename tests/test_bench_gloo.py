@@ -45,14 +45,34 @@ def test_weak_scaling_line_at_world_2():
     assert d["gathered_shape"] == [2 * K, B, L] and d["gathered_checksum"] == want
 
 
-def test_strong_scaling_queue_with_a_ragged_tail_at_world_2():
-    B, L, Q = 8, 16, 37                                   # 19 + 18 crops: a short last batch on both ranks
-    d = _run(2, ["--queue", str(Q), "--batch", str(B), "--max-len", str(L), "--steps", "2", "--warmup", "1"])
+def _strong_want(chunks, B):
+    k = _key(0, B)                                        # strong mode: one set of B crops, every chunk replays it from its first row
+    return sum(5 + int(k[i % B]) + 3 for lo, hi in chunks for i in range(hi - lo))      # ids 2, key, 3 and the length column (3)
+
+
+def test_strong_scaling_queue_is_dealt_in_equal_chunks_at_world_2():
+    """--queue goes through the product dispatcher's chunking (manga_ocr.multi.deal_sizes): 37 crops on two ranks whose engines
+    take 2 x 8 rows are three chunks of 13 + 12 + 12 (no thinner than the 16 rows a child holds), pulled from the shared counter;
+    ragged last batches."""
+    sys.path.insert(0, os.path.join(ROOT, "manga-ocr_amd"))
+    from manga_ocr.multi import deal_sizes
+    B, L, Q = 8, 16, 37
+    d = _run(2, ["--queue", str(Q), "--batch", str(B), "--max-batch", "8", "--lanes", "2", "--max-len", str(L), "--steps", "2", "--warmup", "1"])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["queue"] == Q
     assert abs(d["value"] * d["ms_per_step"] * 1e-3 * d["steps"] - Q) < 1e-6 * Q      # value = the WHOLE queue over the slowest rank's time
-    want = 0
-    for r, n in ((0, 19), (1, 18)):                       # shard_bounds(37, 2): contiguous shards
-        k = _key(r, B)
-        rows = [k[i % B] for i in range(n)]               # every batch of a rank replays its B crops
-        want += sum(5 + int(v) + 3 for v in rows)         # ids 2, key, 3 and the length column (3)
-    assert d["gathered_shape"] == [2 * 19, L + 1] and d["gathered_checksum"] == want
+    chunks = deal_sizes(Q, 2, 16)
+    assert [b - a for a, b in chunks] == [13, 12, 12]
+    deal = d["dealing"]
+    assert deal["policy"] == "equal" and deal["chunks"] == 3 and deal["chunk_rows"] == [13, 12, 12]
+    assert sum(deal["chunks_pulled_per_rank"]) == 3 and len(deal["chunks_pulled_per_rank"]) == 2      # every chunk pulled exactly once
+    assert d["gathered_shape"] == [Q, L + 1] and d["gathered_checksum"] == _strong_want(chunks, B)
+
+
+def test_strong_scaling_queue_guided_chunks_at_world_2():
+    sys.path.insert(0, os.path.join(ROOT, "manga-ocr_amd"))
+    from manga_ocr.multi import deal_sizes
+    B, L, Q = 8, 16, 150
+    d = _run(2, ["--queue", str(Q), "--deal", "guided", "--batch", str(B), "--max-batch", "16", "--lanes", "2", "--max-len", str(L), "--steps", "2", "--warmup", "1"])
+    chunks = deal_sizes(Q, 2, 32, policy="guided")
+    assert d["dealing"]["policy"] == "guided" and d["dealing"]["chunks"] == len(chunks) and sum(d["dealing"]["chunks_pulled_per_rank"]) == len(chunks)
+    assert d["gathered_shape"] == [Q, L + 1] and d["gathered_checksum"] == _strong_want(chunks, B)

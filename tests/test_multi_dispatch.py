@@ -169,7 +169,7 @@ def test_a_child_that_dies_loses_nothing():
     straight into the result block (the collective is not entered with a rank missing), and the handle keeps serving
     on the survivor."""
     crops = _crops(3, 16)
-    crops[4] = np.full((17, 25, 3), 7, np.uint8)       # chunk [4, 6) is the first one dealt to child 1
+    crops[2] = np.full((17, 25, 3), 7, np.uint8)       # chunk [2, 4) is the first one dealt to child 1 (breadth-first dealing)
     eng = MultiGpuEngine([0, 1], factory=fake_factory, factory_args=dict(die_rank=1), backend="gloo", min_chunk=2, max_chunk=2)
     try:
         ids, lens = eng.recognize_images(crops)
@@ -197,17 +197,29 @@ def test_a_child_whose_engine_keeps_failing_is_dropped():
         eng.close()
 
 
-def test_deal_sizes_cover_the_queue_with_shrinking_chunks():
-    for n, world, mx, mn in ((10_000, 8, 4096, 64), (5, 3, 4, 2), (1, 2, 8, 4), (129, 2, 64, 64), (0, 4, 8, 2)):
-        ch = deal_sizes(n, world, mx, mn)
-        assert (not ch and n == 0) or (ch[0][0] == 0 and ch[-1][1] == n)
-        assert all(a[1] == b[0] for a, b in zip(ch, ch[1:]))
-        sizes = [b - a for a, b in ch]
-        assert all(s <= mx for s in sizes) and all(s >= min(mn, n) for s in sizes[:-1])
-        assert sizes[:-1] == sorted(sizes[:-1], reverse=True)
-    # the 10,000-crop queue of BASELINE configs[3] on 8 GPUs whose engines take 2 x 2048 rows: fat chunks first
-    sizes = [b - a for a, b in deal_sizes(10_000, 8, 4096, 64)]
+def test_deal_sizes_cover_the_queue():
+    cases = ((10_000, 8, 4096, 64), (5, 3, 4, 2), (1, 2, 8, 4), (129, 2, 64, 64), (0, 4, 8, 2), (100_000, 8, 5120, 64), (100, 8, 4096, 64))
+    for policy in ("equal", "guided"):
+        for n, world, mx, mn in cases:
+            ch = deal_sizes(n, world, mx, mn, policy=policy)
+            assert (not ch and n == 0) or (ch[0][0] == 0 and ch[-1][1] == n)
+            assert all(a[1] == b[0] for a, b in zip(ch, ch[1:]))
+            sizes = [b - a for a, b in ch]
+            assert all(0 < s <= mx for s in sizes)
+            assert sizes == sorted(sizes, reverse=True) or policy == "guided" and sizes[:-1] == sorted(sizes[:-1], reverse=True)
+            if policy == "guided":
+                assert all(s >= min(mn, n) for s in sizes[:-1])
+            else:
+                assert max(sizes, default=0) - min(sizes, default=0) <= 1           # whole rounds of equal chunks
+    # the 10,000-crop queue of BASELINE configs[3] on 8 GPUs whose engines take 2 x 2048 rows: the static shards, dealt
+    assert [b - a for a, b in deal_sizes(10_000, 8, 4096, 64, policy="equal")] == [1250] * 8
+    # ... three rounds when the queue outgrows what the children hold at once; never thinner than min_chunk while that covers it
+    assert len(deal_sizes(100_000, 8, 5120, 64, policy="equal")) == 24
+    assert [b - a for a, b in deal_sizes(100, 8, 4096, 64, policy="equal")] == [50, 50]
+    sizes = [b - a for a, b in deal_sizes(10_000, 8, 4096, 64, policy="guided")]
     assert sizes[0] == 625 and sizes[-2] >= 64 and len(sizes) >= 16
+    with pytest.raises(ValueError):
+        deal_sizes(10, 2, 4, 2, policy="static")
 
 
 def failing_factory(rank, device, args):
