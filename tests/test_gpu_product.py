@@ -248,3 +248,28 @@ def test_main_process_dispatcher_with_the_real_engine_and_rccl_in_a_child_proces
     np.testing.assert_array_equal(rlens, wl)
     assert rlens[1] == 0
     report("MultiGpuEngine([0]) (child process, RCCL group of one) == in-process engine: ids identical")
+
+
+def test_two_children_on_one_card_are_dealt_a_queue_with_the_real_engine():
+    """The dealing dispatcher with TWO real engines: both children open card 0 (the box has one GPU; two processes share it),
+    the exchange runs over gloo (RCCL refuses two ranks on one device), everything else - spawn, breadth-first dealing of
+    `deal_sizes` chunks, shared-memory hand-over, the all-gather of kept rows - is what MangaOcr(devices=[0..7]) does.  ids
+    equal the in-process engine's on the same chunks (a bf16 engine's kernel regime follows the row count of a call)."""
+    from manga_ocr.multi import MultiGpuEngine, deal_sizes
+    imgs = list(crops(321, 40))
+    fa = dict(synthetic_seed=0, dtype="bf16", max_batch=8, lanes=2)
+    eng = MultiGpuEngine([0, 0], factory_args=fa, backend="gloo")
+    try:
+        ids, lens = eng.recognize_images(imgs)
+        stats = dict(eng.stats)
+    finally:
+        eng.close()
+    chunks = deal_sizes(40, 2, 16)
+    assert [b - a for a, b in chunks] == [14, 13, 13]
+    assert sum(stats["chunks"].values()) == 3 and all(v >= 1 for v in stats["chunks"].values()) and not stats["lost"]
+    ref = engine("bf16", max_batch=8, lanes=2, auto_path=True)
+    for lo, hi in chunks:
+        want, wlens = ref.recognize_images(imgs[lo:hi])
+        np.testing.assert_array_equal(ids[lo:hi], want)
+        np.testing.assert_array_equal(lens[lo:hi], wlens)
+    report(f"MultiGpuEngine([0, 0], gloo): 40 crops dealt as 14 + 13 + 13 to two real engines sharing the card ({stats['chunks']}): ids == in-process engine")
