@@ -157,6 +157,7 @@ struct Lane {
     int np = 0;                     // slots the decode steps run on: n rounded up (graph_rows), the extra ones are born finished; shrinks when the batch is compacted
     int np0 = 0;                    // np at the start of the batch = its kernel regime
     int t = 0, steps = 0, chunk = 0;
+    bool finishing = false;         // a flag of this batch has reported a finished row: rows are leaving, chunks get shorter
     bool flag_pending[2] = {false, false};
     hipEvent_t flag_ev[2] = {nullptr, nullptr};
 };
@@ -1478,6 +1479,7 @@ void start_batch(mocr_engine* e, Lane& L) {
     DecState st = make_state(e, L.max_len, nullptr, 0, nullptr, L.n);
     dec_token<T, true>(e, st, 0, L.np);
     L.t = 0; L.steps = L.max_len - 1; L.chunk = 0;
+    L.finishing = false;
     L.flag_pending[0] = L.flag_pending[1] = false;
 }
 
@@ -1526,15 +1528,39 @@ template <typename T>
 void advance(mocr_engine* e, Lane& L) {
     const bool early = !(e->cfg.flags & MOCR_FLAG_NO_EARLY_EXIT);
     const int slot = L.chunk & 1;
-    if (early && L.flag_pending[slot]) {
-        HIPCHECK(hipEventSynchronize(L.flag_ev[slot]));
-        L.flag_pending[slot] = false;
-        if (e->h_pinned[slot] <= 0) { finish_batch(e, L); return; }
-        if (e->D == 768) compact_rows<T>(e, L, e->h_pinned[slot]);
+    if (early) {
+        // The unfinished-row count this chunk is planned with: the flag of the chunk just before it when that has already
+        // landed (it has whenever another lane's work ran in between - no wait), otherwise the flag two chunks back, waited
+        // for as always (the lane then still has a chunk queued while the host looks).  A fresher count compacts a batch -
+        // and ends it - up to a chunk earlier; when the rows move does not change any id (compact_rows).
+        int unf = -1;
+        const int newer = slot ^ 1;
+        if (L.flag_pending[newer]) {
+            const hipError_t q = hipEventQuery(L.flag_ev[newer]);
+            if (q == hipSuccess) {
+                unf = e->h_pinned[newer];
+                L.flag_pending[newer] = L.flag_pending[slot] = false;      // (the older flag's event precedes it in the stream)
+            } else {
+                (void)hipGetLastError();                                   // hipErrorNotReady is not a failure
+                if (q != hipErrorNotReady) HIPCHECK(q);
+            }
+        }
+        if (unf < 0 && L.flag_pending[slot]) {
+            HIPCHECK(hipEventSynchronize(L.flag_ev[slot]));
+            L.flag_pending[slot] = false;
+            unf = e->h_pinned[slot];
+        }
+        if (unf >= 0) {
+            if (unf <= 0) { finish_batch(e, L); return; }
+            if (unf < L.n) L.finishing = true;
+            if (e->D == 768) compact_rows<T>(e, L, unf);
+        }
     }
     if (L.t >= L.steps) { finish_batch(e, L); return; }
     DecState st = make_state(e, L.max_len, nullptr, 0, nullptr, L.n);
-    const int chunk = chunk_steps(L.np);
+    // (while rows are leaving, half-length chunks: the count a compaction acts on is at most 4 + 4 steps old instead of 8 + 8;
+    // a batch none of whose rows has finished - the synthetic-weights headline - keeps the long chunks)
+    const int chunk = L.finishing ? std::min(chunk_steps(L.np), CHUNK / 2) : chunk_steps(L.np);
     const int k = std::min(chunk, L.steps - L.t);
     const bool use_graph = !e->prof_on && !(e->cfg.flags & MOCR_FLAG_NO_GRAPH);
     if (use_graph && k == chunk) {
