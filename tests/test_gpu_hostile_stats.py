@@ -90,10 +90,13 @@ def test_bf16_encoder_on_a_hostile_residual_stream(kind):
     assert benign[0] and 0.9 < benign[1] < 1.5
 
 
+@pytest.mark.parametrize("path", ["auto", "latent", "fp8"])
 @pytest.mark.parametrize("kind", list(KINDS))
-def test_bf16_teacher_forced_logits_on_hostile_weights(kind):
+def test_bf16_teacher_forced_logits_on_hostile_weights(kind, path):
     """Teacher-forced logits of the 8 golden crops (inside the 256-crop batch, 23 steps) against transformers' own logit
-    columns: the bf16 tolerance of the benign-weights tests must hold."""
+    columns: the bf16 tolerance of the benign-weights tests must hold - on the kernels a 256-row batch takes by itself (classic
+    attention) and on the latent (absorbed K / V) attention of the fat batches the headline runs, whose keys ARE the encoder's
+    output rows with their massive channels."""
     gold = _gold(kind)
     dg = torch.from_numpy(_batch()).cuda()
     torch.cuda.synchronize()
@@ -101,11 +104,12 @@ def test_bf16_teacher_forced_logits_on_hostile_weights(kind):
     forced = np.zeros((ROWS, T + 1), np.int32)
     forced[:8] = gold["ids_len24"][:, :T + 1]
     forced[8:] = gold["ids_len24"][0, :T + 1]
-    eng = engine("bf16", seed=3, hostile=KINDS[kind][0], max_batch=ROWS, auto_path=True)
+    # "fp8": the opt-in e4m3 attention (MOCR_FLAG_FP8_ATTENTION = 128) - its key rows are quantised with ONE scale per tensor
+    eng = engine("bf16", seed=3, hostile=KINDS[kind][0], max_batch=ROWS, auto_path=path == "auto", flags=128 if path == "fp8" else 0)
     got = eng.decode_logits(dg, ROWS, forced[:, :T])[:8][:, :, gold["vocab_cols"]]
     ref = gold["logits_cols"][:, :T]
     d = np.abs(got - ref)
     gap = gold["logits_top2_gap"][:, :T]
-    report(f"teacher-forced logits bf16 on hostile weights '{kind}' (8 golden crops in a {ROWS}-row batch, {T} steps, 64 vocabulary columns) vs "
+    report(f"teacher-forced logits bf16 ({path} attention path) on hostile weights '{kind}' (8 golden crops in a {ROWS}-row batch, {T} steps, 64 vocabulary columns) vs "
            f"transformers: max abs err {d.max():.3e}, mean {d.mean():.3e}; smallest reference top-2 margin {gap.min():.3e}")
-    assert np.isfinite(got).all() and d.max() <= 3e-2
+    assert np.isfinite(got).all() and d.max() <= (6e-2 if path == "fp8" else 3e-2)      # (the fp8 mode's own bound: test_gpu_fp8_attention.py)
