@@ -583,10 +583,12 @@ void gemm(mocr_engine* e, const char* name, const void* A, int lda, const void* 
         const int strip = tile >= 4099 ? 1 : tile == 4097 ? 0 : strip_env;
         // the bf16-epilogue GEMMs: 1 = the one-barrier-per-two-K-tiles loop with the 64-deep LDS image (K64), 0 = one barrier per
         // 32-deep K-tile, three K-tiles in flight (r03 first session's choice, when both loops fed on half-line requests)
+#ifdef MOCR_EXPERIMENTS
         static const int pair_bf16 = env_int("MOCR_GEMM_PAIR_BF16", 1);
-        if (epi == EPI_BIAS_RESID) launch_gemm_pers<true, true>(e, p, epi, blocks, strip);
-        else if (pair_bf16) launch_gemm_pers<true, true>(e, p, epi, blocks, strip);
-        else launch_gemm_pers<true, false>(e, p, epi, blocks, strip);
+        if (epi != EPI_BIAS_RESID && !pair_bf16) launch_gemm_pers<true, false>(e, p, epi, blocks, strip);
+        else
+#endif
+        launch_gemm_pers<true, true>(e, p, epi, blocks, strip);
     }
 #ifdef MOCR_EXPERIMENTS
     else if (tile == 4098) launch_gemm_pers<false>(e, p, epi, 0);   // experiment: every wave requests LDS-DMA
@@ -999,12 +1001,14 @@ void launch_latent(mocr_engine* e, bool self, const LatentParams& p) {
     if (e->lat_tk == 18) {          // the default: three blocks per CU on two-slot rings
         if (self) hipLaunchKernelGGL((latent_attnT_kernel<true, 2>), dim3(grid), dim3(256), LATT_LDS_OF(2), e->stream, p);
         else hipLaunchKernelGGL((latent_attnT_kernel<false, 2>), dim3(grid), dim3(256), LATT_LDS_OF(2), e->stream, p);
+#ifdef MOCR_EXPERIMENTS
     } else if (e->lat_tk == 17) {
         if (self) hipLaunchKernelGGL(latent_attnT_kernel<true>, dim3(grid), dim3(256), LATT_LDS, e->stream, p);
         else hipLaunchKernelGGL(latent_attnT_kernel<false>, dim3(grid), dim3(256), LATT_LDS, e->stream, p);
     } else if (e->lat_tk == 16) {
         if (self) hipLaunchKernelGGL((latent_attn_kernel<true, 16>), dim3(grid), dim3(256), LatCfg<16>::LDS, e->stream, p);
         else hipLaunchKernelGGL((latent_attn_kernel<false, 16>), dim3(grid), dim3(256), LatCfg<16>::LDS, e->stream, p);
+#endif
     } else {
         if (self) hipLaunchKernelGGL((latent_attn_kernel<true, 32>), dim3(grid), dim3(256), LatCfg<32>::LDS, e->stream, p);
         else hipLaunchKernelGGL((latent_attn_kernel<false, 32>), dim3(grid), dim3(256), LatCfg<32>::LDS, e->stream, p);
@@ -1320,20 +1324,10 @@ template <typename T> void init_kernel_attrs() {
     set_max_lds(gemm_wide2_kernel<EPI_BIAS_GELU>, 4 * (256 + 256) * 64);
     set_max_lds(gemm_wide2_kernel<EPI_BIAS_RESID>, 4 * (256 + 256) * 64);
 #endif
-    set_max_lds(gemm_pers_kernel<EPI_BIAS, true>, PERS_LDS);
-    set_max_lds(gemm_pers_kernel<EPI_BIAS_GELU, true>, PERS_LDS);
-    set_max_lds(gemm_pers_kernel<EPI_BIAS_RESID, true>, PERS_LDS);
     set_max_lds(gemm_pers_kernel<EPI_BIAS_RESID, true, true>, PERS_LDS);
     set_max_lds(gemm_pers_kernel<EPI_BIAS_RESID, true, true, true>, PERS_LDS);
     set_max_lds(gemm_pers_kernel<EPI_BIAS_RESID, true, true, true, true>, PERS_LDS);
     set_max_lds(gemm_pers_kernel<EPI_BIAS_RESID, true, true, false, true>, PERS_LDS);
-    set_max_lds(gemm_pers_kernel<EPI_BIAS, true, false, false, true>, PERS_LDS);
-    set_max_lds(gemm_pers_kernel<EPI_BIAS_GELU, true, false, false, true>, PERS_LDS);
-    set_max_lds(gemm_pers_kernel<EPI_BIAS, true, false, true, true>, PERS_LDS);
-    set_max_lds(gemm_pers_kernel<EPI_BIAS_GELU, true, false, true, true>, PERS_LDS);
-    set_max_lds(gemm_pers_kernel<EPI_BIAS, true, false, true>, PERS_LDS);
-    set_max_lds(gemm_pers_kernel<EPI_BIAS_GELU, true, false, true>, PERS_LDS);
-    set_max_lds(gemm_pers_kernel<EPI_BIAS_RESID, true, false, true>, PERS_LDS);
     set_max_lds(gemm_pers_kernel<EPI_BIAS, true, true>, PERS_LDS);
     set_max_lds(gemm_pers_kernel<EPI_BIAS_GELU, true, true>, PERS_LDS);
     set_max_lds(gemm_pers_kernel<EPI_BIAS, true, true, false, true>, PERS_LDS);
@@ -1343,6 +1337,17 @@ template <typename T> void init_kernel_attrs() {
     set_max_lds(gemm_pers_kernel<EPI_BIAS, true, true, true>, PERS_LDS);
     set_max_lds(gemm_pers_kernel<EPI_BIAS_GELU, true, true, true>, PERS_LDS);
 #ifdef MOCR_EXPERIMENTS
+    // (the one-barrier-per-K-tile loop on the 32-deep image: A/B partner of the pair loop)
+    set_max_lds(gemm_pers_kernel<EPI_BIAS, true>, PERS_LDS);
+    set_max_lds(gemm_pers_kernel<EPI_BIAS_GELU, true>, PERS_LDS);
+    set_max_lds(gemm_pers_kernel<EPI_BIAS_RESID, true>, PERS_LDS);
+    set_max_lds(gemm_pers_kernel<EPI_BIAS, true, false, false, true>, PERS_LDS);
+    set_max_lds(gemm_pers_kernel<EPI_BIAS_GELU, true, false, false, true>, PERS_LDS);
+    set_max_lds(gemm_pers_kernel<EPI_BIAS, true, false, true, true>, PERS_LDS);
+    set_max_lds(gemm_pers_kernel<EPI_BIAS_GELU, true, false, true, true>, PERS_LDS);
+    set_max_lds(gemm_pers_kernel<EPI_BIAS, true, false, true>, PERS_LDS);
+    set_max_lds(gemm_pers_kernel<EPI_BIAS_GELU, true, false, true>, PERS_LDS);
+    set_max_lds(gemm_pers_kernel<EPI_BIAS_RESID, true, false, true>, PERS_LDS);
     set_max_lds(gemm_pers_kernel<EPI_BIAS, false, true>, PERS_LDS);
     set_max_lds(gemm_pers_kernel<EPI_BIAS_GELU, false, true>, PERS_LDS);
     set_max_lds(gemm_pers_kernel<EPI_BIAS_RESID, false, true>, PERS_LDS);
@@ -1360,10 +1365,12 @@ template <typename T> void init_kernel_attrs() {
     set_max_lds(smallm_gemm_kernel<SM_PRO_LN, SM_EPI_GELU_F32, 2, 3>, SM_LDS(SM_PRO_LN, 2));
     set_max_lds(latent_attn_kernel<true, 32>, LatCfg<32>::LDS);
     set_max_lds(latent_attn_kernel<false, 32>, LatCfg<32>::LDS);
+#ifdef MOCR_EXPERIMENTS
     set_max_lds(latent_attn_kernel<true, 16>, LatCfg<16>::LDS);
     set_max_lds(latent_attn_kernel<false, 16>, LatCfg<16>::LDS);
     set_max_lds(latent_attnT_kernel<true>, LATT_LDS);
     set_max_lds(latent_attnT_kernel<false>, LATT_LDS);
+#endif
     set_max_lds((latent_attnT_kernel<true, 2>), LATT_LDS_OF(2));
     set_max_lds((latent_attnT_kernel<false, 2>), LATT_LDS_OF(2));
     set_max_lds(latent_attn_fp8_kernel<true>, LAT8_LDS);
