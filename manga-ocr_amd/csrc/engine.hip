@@ -331,13 +331,16 @@ void launch_gemm_t(mocr_engine* e, const GemmParams& p0, int split, int ybatch) 
     // K-tile.  A four-slot ring (three K-tiles in flight instead of one) was built to hide a memory round trip there and
     // changed nothing (r02: QKV of one crop 16.1 vs 15.9 us, FC2 40.4 vs 40.1): the cost is the DMA issue, not the
     // latency - what helped is smaller tiles (run_encoder).  Kept for experiments: MOCR_GEMM_DEEP=1
+#ifdef MOCR_EXPERIMENTS
     static const int deep = env_int("MOCR_GEMM_DEEP", 0);
     const int ktiles = p.k_per_split / (128 / (int)sizeof(T));
     if (deep && ktiles >= 4 && (long long)grid.x * grid.y * grid.z <= e->num_cus) {
         hipLaunchKernelGGL((gemm_kernel<T, BM, BN, EPI, 4>), grid, dim3(256), 4 * (BM + BN) * 128, e->stream, p);
-    } else {
-        hipLaunchKernelGGL((gemm_kernel<T, BM, BN, EPI, NST>), grid, dim3(256), lds, e->stream, p);
+        HIPCHECK(hipGetLastError());
+        return;
     }
+#endif
+    hipLaunchKernelGGL((gemm_kernel<T, BM, BN, EPI, NST>), grid, dim3(256), lds, e->stream, p);
     HIPCHECK(hipGetLastError());
 }
 
@@ -1291,6 +1294,7 @@ template <typename T> void init_kernel_attrs() {
     set_max_lds(gemm_kernel<T, 64, 64, EPI_PATCH, 2>, l64);
     set_max_lds(gemm_kernel<T, 64, 64, EPI_BIAS_F32, 2>, l64);
     set_max_lds(gemm_kernel<T, 64, 64, EPI_ARGMAX, 2>, l64);
+#ifdef MOCR_EXPERIMENTS
     set_max_lds(gemm_kernel<T, 128, 128, EPI_SLAB, 4>, 2 * l128);
     set_max_lds(gemm_kernel<T, 128, 128, EPI_BIAS, 4>, 2 * l128);
     set_max_lds(gemm_kernel<T, 128, 128, EPI_BIAS_GELU, 4>, 2 * l128);
@@ -1305,6 +1309,7 @@ template <typename T> void init_kernel_attrs() {
     set_max_lds(gemm_kernel<T, 64, 64, EPI_PATCH, 4>, 2 * l64);
     set_max_lds(gemm_kernel<T, 64, 64, EPI_BIAS_F32, 4>, 2 * l64);
     set_max_lds(gemm_kernel<T, 64, 64, EPI_ARGMAX, 4>, 2 * l64);
+#endif
     set_max_lds(enc_attn_simple_kernel<T>, (200 * 65 + 200 * 64 + 4 * 64 + 4 * 256) * 4);
     set_max_lds(enc_attn2_kernel, EA2_LDS);
     set_max_lds(enc_attn_f32_kernel, EAF_LDS);
