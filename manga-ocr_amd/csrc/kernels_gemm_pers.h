@@ -155,6 +155,9 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
     if ((ablate & 32768) && dma_wave) __builtin_amdgcn_s_setprio(1);
     if ((ablate & 65536) && !dma_wave) __builtin_amdgcn_s_setprio(1);
 #endif
+    // diagnostics (MOCR_GEMM_ABLATE & 131072 / 262144): the requesting waves / the store waves skip half of their MFMAs (wrong
+    // products; timing only) - is the K loop bound by the requesting waves' chain of MFMAs + requests?
+    const bool skip23 = ((ablate & 131072) && dma_wave) || ((ablate & 262144) && !dma_wave);
     const int nt = p.k_per_split / 32;            // even, >= 4 (checked on the host)
     const size_t a_row = (size_t)p.lda * 2, w_row = (size_t)p.ldw * 2;
     const bool guard = STRIP || (p.M & (BM - 1)) != 0;
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
         __builtin_amdgcn_s_barrier();                                                                                  \
         asm volatile("" ::: "memory");                                                                                 \
         MOCR_W2_READ_HEAD(NXT, offA + sn - hadj_k, offB + sn);      /* hadj_k: of the tile K-tile g + 1 belongs to */   \
-        if (!(STRIP && half)) {                           /* a half tile's wave owns 64 rows: m-tiles 0..3 */           \
+        if (!(STRIP && half) && !skip23) {                           /* a half tile's wave owns 64 rows: m-tiles 0..3 */           \
             MOCR_W2_GROUP(CUR, 2);                                                                                     \
             MOCR_W2_GROUP(CUR, 3);                                                                                     \
         }                                                                                                              \
@@ -345,7 +348,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
         MOCR_W2_GROUP(CUR, 1);                                                                                         \
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(CUR.fa[4]), "+v"(CUR.fa[5]), "+v"(CUR.fa[6]), "+v"(CUR.fa[7]));     \
         MOCR_W2_READ_HEAD(NXT, offA + sn - hadj, offB + sn);     /* K-tile g + 1 (same tile): proved landed by the last barrier */ \
-        if (!(STRIP && half)) {                           /* a half tile's wave owns 64 rows: m-tiles 0..3 */           \
+        if (!(STRIP && half) && !skip23) {                           /* a half tile's wave owns 64 rows: m-tiles 0..3 */           \
             MOCR_W2_GROUP(CUR, 2);                                                                                     \
             MOCR_W2_GROUP(CUR, 3);                                                                                     \
         }                                                                                                              \
@@ -367,7 +370,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
         asm volatile("" ::: "memory");                                                                                 \
         stage_next();                                     /* K-tile g + 3 into the slot of K-tile g - 1 */              \
         MOCR_W2_READ_HEAD(NXT, offA + sn - hadj_h, offB + sn);      /* K-tile g + 1: the NEXT tile's when this is the tile's last */ \
-        if (!(STRIP && half)) {                                                                                        \
+        if (!(STRIP && half) && !skip23) {                                                                                        \
             MOCR_W2_GROUP(CUR, 2);                                                                                     \
             MOCR_W2_GROUP(CUR, 3);                                                                                     \
         }                                                                                                              \
@@ -405,7 +408,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
         MOCR_W2_GROUP(CUR, 1);                                                                                         \
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(CUR.fa[4]), "+v"(CUR.fa[5]), "+v"(CUR.fa[6]), "+v"(CUR.fa[7]));     \
         MOCR_W2K_READ_HEAD(NXT, (offA + st - hadj) ^ 64u, (offB + st) ^ 64u);      /* k-step 1 of the same tile */       \
-        if (!(STRIP && half)) {                                                                                        \
+        if (!(STRIP && half) && !skip23) {                                                                                        \
             MOCR_W2_GROUP(CUR, 2);                                                                                     \
             MOCR_W2_GROUP(CUR, 3);                                                                                     \
         }                                                                                                              \
@@ -429,7 +432,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pers_kernel(GemmParams p) {
         MOCR_STAMP(2);                                                                                                 \
         stage_next();                                     /* batch g + 3: the A rows of tile (g >> 1) + 2, into this tile's slot */ \
         MOCR_W2K_READ_HEAD(NXT, offA + sn - hadj_h, offB + sn);                                                        \
-        if (!(STRIP && half)) {                                                                                        \
+        if (!(STRIP && half) && !skip23) {                                                                                        \
             MOCR_W2_GROUP(CUR, 2);                                                                                     \
             MOCR_W2_GROUP(CUR, 3);                                                                                     \
         }                                                                                                              \
