@@ -349,9 +349,9 @@ def main():
         eng.profile_enable(True)
         eng.profile_reset()
         # ONE internal batch of the shape the timed region's lanes ran (the engine splits a queue over its idle lanes
-        # while every part keeps >= 1024 rows), alone on the GPU: durations free of overlap
+        # while every part keeps >= 1280 rows: engine.hip pump_once SPLIT_MIN), alone on the GPU: durations free of overlap
         rows_q = min(args.max_batch * args.lanes, steps_timed * B)
-        parts = max(1, min(args.lanes, rows_q // 1024))
+        parts = max(1, min(args.lanes, rows_q // 1280))
         psteps = max(1, min(args.max_batch // B, -(-steps_timed // parts)))
         for i in range(psteps):
             eng.recognize_device(d_gray, B, d_ids[i % K], d_len[i % K])

@@ -1608,9 +1608,11 @@ bool pump_once(mocr_engine* e) {
             // queue would fit into fewer of them, it is split evenly over the idle lanes as long as every part keeps
             // >= SPLIT_MIN rows: two fat batches in flight overlap each other's latency-bound phases (+6 % at 2 x 2560
             // against 1 x 5120 rows, r02), while below that merging beats overlapping.
-            // (r03: 600 instead of 1024 - the 1250 rows a rank of the 8-GPU queue run gets decode as 2 x 625 in 258 ms
-            // instead of 270 ms as one batch)
-            static const long long SPLIT_MIN = env_int("MOCR_SPLIT_MIN", 600);
+            // (r03: 600 instead of 1024 - the 1250 rows a rank of the 8-GPU queue run gets decoded as 2 x 625 in 258 ms
+            // instead of 270 ms as one batch.  r04, with three attention blocks per CU and the fused query kernel from 512
+            // rows, tools/r04_probe_lanes.sh: 1250 rows as ONE batch 216-221 ms against 229-231 ms as 2 x 625; 2500 rows 370-378
+            // as one against 374-381 as 2 x 1250 (3 x 833: 390); 2 x 2560 against 1 x 5120: +5.5 %.  Parts below ~1280 rows lose.)
+            static const long long SPLIT_MIN = env_int("MOCR_SPLIT_MIN", 1280);
             long long rows_pending = 0;
             for (const Job& p : e->pending) rows_pending += p.n;
             int idle = 0;
