@@ -856,9 +856,10 @@ void run_encoder(mocr_engine* e, const uint8_t* d_gray, int n) {
 // ---------------------------------------------------------------------------------------- decoder
 static int dec_tile(int rows) {
     static const int forced = env_int("MOCR_DEC_TILE", 0);
-    // 128 x 128 tiles from 512 rows (r02: at 256 rows the 64 x 64 tiles need a third of the split-K slabs - 113 -> 101 ms
-    // for an isolated 256-crop batch)
-    static const int fat = env_int("MOCR_DEC_FAT_ROWS", 512);
+    // 128 x 128 tiles from 1024 rows (r02: from 512 - at 256 rows the 64 x 64 tiles need a third of the split-K slabs, 113 -> 101
+    // ms for an isolated 256-crop batch.  r04, tools/r04_dectile_ab.sh, isolated batches, 64 / 128 tiles: 512 rows 128.0 / 134.3
+    // ms, 640 rows 143.4 / 147.4, 768 rows 157.5 / 162.7, 1024 rows 199.8 / 195.4, 1280 rows 229 / 224)
+    static const int fat = env_int("MOCR_DEC_FAT_ROWS", 1024);
     if (forced) return forced;
     return rows >= fat ? 128 : 64;
 }
