@@ -327,20 +327,21 @@ void launch_gemm_t(mocr_engine* e, const GemmParams& p0, int split, int ybatch) 
     constexpr int NST = gemm_ring<BM>();
     constexpr int lds = NST * (BM + BN) * 128;
     dim3 grid(ntm * p.ntn, ybatch, split);
-    // Small grids (at most one block per CU: the encoder of a few crops) walk their K-tiles alone on a CU at ~1 us per
-    // K-tile.  A four-slot ring (three K-tiles in flight instead of one) was built to hide a memory round trip there and
-    // changed nothing (r02: QKV of one crop 16.1 vs 15.9 us, FC2 40.4 vs 40.1): the cost is the DMA issue, not the
-    // latency - what helped is smaller tiles (run_encoder).  Kept for experiments: MOCR_GEMM_DEEP=1
-#ifdef MOCR_EXPERIMENTS
-    static const int deep = env_int("MOCR_GEMM_DEEP", 0);
+    // Grids of at most one block per CU walk their K-tiles alone on a CU, one memory round trip per K-tile on the two-slot
+    // ring.  A four-slot ring (three K-tiles in flight, 128 KiB of LDS for the 128 x 128 tile) changed nothing for the encoder
+    // of a few crops (r02: QKV of one crop 16.1 vs 15.9 us - its cost is the DMA issue), but the decode step's split-K
+    // projections of a batch decoding ALONE are such grids too (240 blocks x 6-24 K-tiles at 2560 rows): r04,
+    // tools/r04_deep_ab.sh, isolated batches, two / four slots: 128 rows 68.0 / 66.2 ms, 256 rows 90.6 / 88.6, 320 rows 108.5 /
+    // 104.7, 512 rows 128.5 / 122.4, 1024 rows 196.0 / 193.7 - and the headline's two lanes x 2560 rows 7.02-7.11 / 6.90-6.92 k
+    // crops/s: two 64-KiB blocks of two lanes share a CU, a 128-KiB block does not.  So: four slots for batches below the
+    // rows from which a queue is split over two lanes (1280).  Same K order, same sums: bit-identical either way.
+    static const int deep_rows = env_int("MOCR_GEMM_DEEP_ROWS", 1280);
     const int ktiles = p.k_per_split / (128 / (int)sizeof(T));
-    if (deep && ktiles >= 4 && (long long)grid.x * grid.y * grid.z <= e->num_cus) {
+    if (e->rrows(p.M) < deep_rows && ktiles >= 4 && (long long)grid.x * grid.y * grid.z <= e->num_cus) {
         hipLaunchKernelGGL((gemm_kernel<T, BM, BN, EPI, 4>), grid, dim3(256), 4 * (BM + BN) * 128, e->stream, p);
-        HIPCHECK(hipGetLastError());
-        return;
+    } else {
+        hipLaunchKernelGGL((gemm_kernel<T, BM, BN, EPI, NST>), grid, dim3(256), lds, e->stream, p);
     }
-#endif
-    hipLaunchKernelGGL((gemm_kernel<T, BM, BN, EPI, NST>), grid, dim3(256), lds, e->stream, p);
     HIPCHECK(hipGetLastError());
 }
 
@@ -1295,7 +1296,6 @@ template <typename T> void init_kernel_attrs() {
     set_max_lds(gemm_kernel<T, 64, 64, EPI_PATCH, 2>, l64);
     set_max_lds(gemm_kernel<T, 64, 64, EPI_BIAS_F32, 2>, l64);
     set_max_lds(gemm_kernel<T, 64, 64, EPI_ARGMAX, 2>, l64);
-#ifdef MOCR_EXPERIMENTS
     set_max_lds(gemm_kernel<T, 128, 128, EPI_SLAB, 4>, 2 * l128);
     set_max_lds(gemm_kernel<T, 128, 128, EPI_BIAS, 4>, 2 * l128);
     set_max_lds(gemm_kernel<T, 128, 128, EPI_BIAS_GELU, 4>, 2 * l128);
@@ -1310,7 +1310,6 @@ template <typename T> void init_kernel_attrs() {
     set_max_lds(gemm_kernel<T, 64, 64, EPI_PATCH, 4>, 2 * l64);
     set_max_lds(gemm_kernel<T, 64, 64, EPI_BIAS_F32, 4>, 2 * l64);
     set_max_lds(gemm_kernel<T, 64, 64, EPI_ARGMAX, 4>, 2 * l64);
-#endif
     set_max_lds(enc_attn_simple_kernel<T>, (200 * 65 + 200 * 64 + 4 * 64 + 4 * 256) * 4);
     set_max_lds(enc_attn2_kernel, EA2_LDS);
     set_max_lds(enc_attn_f32_kernel, EAF_LDS);
