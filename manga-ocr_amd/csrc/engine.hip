@@ -337,7 +337,8 @@ void launch_gemm_t(mocr_engine* e, const GemmParams& p0, int split, int ybatch) 
     // rows from which a queue is split over two lanes (1280).  Same K order, same sums: bit-identical either way.
     static const int deep_rows = env_int("MOCR_GEMM_DEEP_ROWS", 1280);
     const int ktiles = p.k_per_split / (128 / (int)sizeof(T));
-    if (e->rrows(p.M) < deep_rows && ktiles >= 4 && (long long)grid.x * grid.y * grid.z <= e->num_cus) {
+    static const int deep_mult64 = env_int("MOCR_GEMM_DEEP_MULT64", 1);      // (experiments: 64 x 64 tiles, two 64-KiB rings fit a CU)
+    if (e->rrows(p.M) < deep_rows && ktiles >= 4 && (long long)grid.x * grid.y * grid.z <= (long long)e->num_cus * (BM == 64 ? deep_mult64 : 1)) {
         hipLaunchKernelGGL((gemm_kernel<T, BM, BN, EPI, 4>), grid, dim3(256), 4 * (BM + BN) * 128, e->stream, p);
     } else {
         hipLaunchKernelGGL((gemm_kernel<T, BM, BN, EPI, NST>), grid, dim3(256), lds, e->stream, p);
