@@ -1085,6 +1085,16 @@ void latent_attn(mocr_engine* e, bool self, int layer, int n, int approx_len) {
     launch_latent(e, self, p);
 }
 
+// The fused query launch (kernels_qqt.h): blocks of 64 rows for batches of up to MOCR_QQT_BM64_ROWS rows (a 16-KiB K-tile, seven
+// in flight, twice the blocks: r04, tools/r04_qqt_bm_ab.sh), of 128 rows above - there every CU has a block either way and the
+// 128-row block reads each weight tile for twice the rows.  `regime_rows` = the row count the choice is made by.
+void launch_qqt(mocr_engine* e, const QqtParams& q, int n, int regime_rows) {
+    static const int bm64_rows = env_int("MOCR_QQT_BM64_ROWS", 1280);
+    if (regime_rows <= bm64_rows) hipLaunchKernelGGL(dec_qqt_kernel<64>, dim3((n + 63) / 64, 12), dim3(256), QqtCfg<64>::LDS, e->stream, q);
+    else hipLaunchKernelGGL(dec_qqt_kernel<128>, dim3((n + 127) / 128, 12), dim3(256), env_int("MOCR_QQT_LDS", QQT_LDS), e->stream, q);
+    HIPCHECK(hipGetLastError());
+}
+
 // q -> Qt -> latent attention -> ctx: the attention block of the latent path up to (not including)
 // the output projection.  wq/bq: query projection; wkT: (Wk^T)/8; wv/bv: value projection.
 void latent_block(mocr_engine* e, bool self, int layer, int n, int t, const void* xin, const void* wq, const float* bq,
@@ -1102,9 +1112,7 @@ void latent_block(mocr_engine* e, bool self, int layer, int n, int t, const void
         q.wkT = reinterpret_cast<const bf16_t*>(wkT); q.qt = reinterpret_cast<bf16_t*>(e->qt);
         {
             ProfScope ps(e, "dec_qqt", 4.0 * n * D * D, (double)n * D * 2 + 2.0 * D * D * 2 + (double)n * e->H * D * 2);
-            static const int qqt_lds = env_int("MOCR_QQT_LDS", QQT_LDS);
-            hipLaunchKernelGGL(dec_qqt_kernel, dim3((n + 127) / 128, e->H), dim3(256), qqt_lds, e->stream, q);
-            HIPCHECK(hipGetLastError());
+            launch_qqt(e, q, n, e->rrows(n));
         }
         latent_attn(e, self, layer, n, self ? t + 1 : e->S);
         HeadBatch hc2; hc2.heads = e->H; hc2.a_yoff = D; hc2.w_yoff = (long long)64 * D; hc2.o_yoff = 64; hc2.b_yoff = 64; hc2.ldw = D;
@@ -1317,7 +1325,8 @@ template <typename T> void init_kernel_attrs() {
 #ifdef MOCR_EXPERIMENTS
     set_max_lds(enc_attn_mfma_kernel, ENC_SP * 128 + 64 * ENC_VT_LD * 2);
 #endif
-    set_max_lds(dec_qqt_kernel, 160 * 1024);
+    set_max_lds(dec_qqt_kernel<128>, 160 * 1024);
+    set_max_lds(dec_qqt_kernel<64>, 160 * 1024);
 #ifdef MOCR_EXPERIMENTS
     constexpr int l256 = 3 * (256 + 128) * 128;
     set_max_lds(gemm_wide_kernel<EPI_BIAS, 2>, 3 * (256 + 128) * 64);
@@ -2729,8 +2738,7 @@ int mocr_op_qqt(mocr_engine* e, const void* d_x, const void* d_wq, const float* 
         q.x = reinterpret_cast<const bf16_t*>(d_x); q.wq = reinterpret_cast<const bf16_t*>(d_wq); q.bq = d_bq;
         q.wkT = reinterpret_cast<const bf16_t*>(d_wkT); q.qt = reinterpret_cast<bf16_t*>(d_qt);
         ProfScope ps(e, "op_qqt", 4.0 * n * 768 * 768, 0);
-        hipLaunchKernelGGL(dec_qqt_kernel, dim3((n + 127) / 128, 12), dim3(256), env_int("MOCR_QQT_LDS", QQT_LDS), e->stream, q);
-        HIPCHECK(hipGetLastError());
+        launch_qqt(e, q, n, n);
         HIPCHECK(hipStreamSynchronize(e->stream));
     });
 }

@@ -407,10 +407,10 @@ def test_latent_attention(L, n, tile):
     assert np.isfinite(got).all() and err <= 3e-2
 
 
-@pytest.mark.parametrize("n", [128, 300, 1024])
+@pytest.mark.parametrize("n", [128, 300, 1024, 1408])
 def test_fused_query_kernel(n):
     """dec_qqt_kernel: Qt[m][h] = bf16(x[m] Wq_h^T + bq_h) . wkT_h for the 12 heads, against float64 numpy with the same
-    intermediate bf16 rounding of q."""
+    intermediate bf16 rounding of q.  Up to 1280 rows the launch runs on 64-row blocks (eight-slot ring), above on 128-row blocks."""
     eng = engine("bf16")
     rs = np.random.RandomState(n)
     D, H = 768, 12
