@@ -1105,7 +1105,9 @@ void latent_block(mocr_engine* e, bool self, int layer, int n, int t, const void
     // two-launch path.  MOCR_DEC_QQT_ROWS = rows from which it is used (0 = never)
     // (r04, tools/r04_qqt_rows_ab.sh, isolated batch, two launches / fused: 512 rows 136.2 / 134.9 ms, 768 rows 165.4 / 163.5, below
     // 512 rows the two launches stay ahead: the switch moved from 1024 to 512 rows)
-    static const int qqt_rows = env_int("MOCR_DEC_QQT_ROWS", 512);
+    // (r04, 64-row blocks, tools/r04_qqt_rows_ab2.sh, two launches / fused: 288 rows 103.6 / 100.4 ms, 320 rows 105.0 / 101.5, 384 rows
+    // 107.7 / 104.6, 448 and 512 rows equal: every latent batch - 257 rows and up - takes the fused launch)
+    static const int qqt_rows = env_int("MOCR_DEC_QQT_ROWS", 257);
     if (qqt_rows > 0 && e->rrows(n) >= qqt_rows && D == 768 && e->H == 12 && !(e->cfg.flags & MOCR_FLAG_NO_FUSED_QQT)) {
         QqtParams q{};
         q.x = reinterpret_cast<const bf16_t*>(xin); q.wq = reinterpret_cast<const bf16_t*>(wq); q.bq = bq;
@@ -1450,7 +1452,7 @@ static int chunk_steps(int rows) {
 }
 
 // Decode graphs are keyed by row count.  Callers submit any n in 1..max_batch (the batcher of MangaOcr, the crop-job
-// queue), so n is rounded up to a coarse grid before it becomes a key: at most ~40 distinct row counts per engine
+// queue), so n is rounded up to a coarse grid before it becomes a key: at most ~50 distinct row counts per engine
 // instead of max_batch, i.e. a bounded number of captures / instantiated graphs, and a batch of 37 crops replays the
 // graph a batch of 40 captured.  The padding costs <= 12.5 % more rows in the (latency-bound) decode steps.
 static int graph_rows(int n, int max_batch) {
@@ -1458,7 +1460,12 @@ static int graph_rows(int n, int max_batch) {
     if (n <= 8) q = 1;
     else if (n <= 64) q = 8;
     else if (n <= 256) q = 32;
-    else if (n <= 1024) q = 128;
+    else if (n <= 1024) {
+        // (r04: 64 instead of 128 - a 288-row batch decoded on 384 slots.  tools/r04_graphq_ab.sh, isolated batches, 128 / 64:
+        // 272-320 rows 100-102 / 95-97 ms, 416-448 rows 113-116 / 109-111, 544 rows 128.6 / 126.6, 700 rows 148 / 145)
+        static const int q_mid = env_int("MOCR_GRAPH_Q_MID", 64);
+        q = q_mid;
+    }
     else q = 256;       // (r04: 512 until rows were compacted - a batch now passes through these row counts on its way down)
     return std::min(round_up(n, q), max_batch);
 }
