@@ -876,7 +876,9 @@ static int pick_split(int N, int K, int kt, int rows, long long slab_cap_per_row
     // behind them is bound by its slab traffic (bench 6.30-6.36 k -> 6.44-6.45 k crops/s; targets 60 / 100 / 450 / 600: 6.30 /
     // 6.32 / 6.35 / 6.10 k)
     static const int target_env = env_int("MOCR_DEC_BLOCKS", 0);
-    const int target = target_env ? target_env : (rows >= 2048 ? 200 : 150);
+    // (r04, with the four-slot rings of lone batches, tools/r04_decblocks_small_ab.sh, targets 150 / 100: 96 rows 58.4 / 56.4 ms,
+    // 128 rows 66.3 / 63.0, 40 / 64 / 192 / 256 rows equal; 320 and 768 rows lose with 100)
+    const int target = target_env ? target_env : (rows >= 2048 ? 200 : rows <= 128 ? 100 : 150);
     const int tile = dec_tile(rows);
     const int tiles = (N / tile) * ((rows + tile - 1) / tile);
     const int ktiles = K / kt;
