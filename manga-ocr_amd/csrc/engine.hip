@@ -338,7 +338,11 @@ void launch_gemm_t(mocr_engine* e, const GemmParams& p0, int split, int ybatch) 
     static const int deep_rows = env_int("MOCR_GEMM_DEEP_ROWS", 1280);
     const int ktiles = p.k_per_split / (128 / (int)sizeof(T));
     static const int deep_mult64 = env_int("MOCR_GEMM_DEEP_MULT64", 1);      // (experiments: 64 x 64 tiles, two 64-KiB rings fit a CU)
-    if (e->rrows(p.M) < deep_rows && ktiles >= 4 && (long long)grid.x * grid.y * grid.z <= (long long)e->num_cus * (BM == 64 ? deep_mult64 : 1)) {
+    // (the ring depth does not touch the arithmetic, so a compacted batch's tail chooses it by the rows it has LEFT, as
+    // launch_qqt its rows per block: r04, tools/r04_neutral_ab.sh, mixed-lengths leg 11.93 -> 12.11 k crops/s, ids bit-identical;
+    // MOCR_NEUTRAL_BY_ROWS=0: by the batch's regime)
+    static const int neutral_by_rows = env_int("MOCR_NEUTRAL_BY_ROWS", 1);
+    if ((neutral_by_rows ? p.M : e->rrows(p.M)) < deep_rows && ktiles >= 4 && (long long)grid.x * grid.y * grid.z <= (long long)e->num_cus * (BM == 64 ? deep_mult64 : 1)) {
         hipLaunchKernelGGL((gemm_kernel<T, BM, BN, EPI, 4>), grid, dim3(256), 4 * (BM + BN) * 128, e->stream, p);
     } else {
         hipLaunchKernelGGL((gemm_kernel<T, BM, BN, EPI, NST>), grid, dim3(256), lds, e->stream, p);
@@ -1116,7 +1120,8 @@ void latent_block(mocr_engine* e, bool self, int layer, int n, int t, const void
         q.wkT = reinterpret_cast<const bf16_t*>(wkT); q.qt = reinterpret_cast<bf16_t*>(e->qt);
         {
             ProfScope ps(e, "dec_qqt", 4.0 * n * D * D, (double)n * D * 2 + 2.0 * D * D * 2 + (double)n * e->H * D * 2);
-            launch_qqt(e, q, n, e->rrows(n));
+            static const int neutral_by_rows = env_int("MOCR_NEUTRAL_BY_ROWS", 1);
+            launch_qqt(e, q, n, neutral_by_rows ? n : e->rrows(n));
         }
         latent_attn(e, self, layer, n, self ? t + 1 : e->S);
         HeadBatch hc2; hc2.heads = e->H; hc2.a_yoff = D; hc2.w_yoff = (long long)64 * D; hc2.o_yoff = 64; hc2.b_yoff = 64; hc2.ldw = D;
