@@ -341,7 +341,7 @@ void launch_gemm_t(mocr_engine* e, const GemmParams& p0, int split, int ybatch) 
     // (the ring depth does not touch the arithmetic, so a compacted batch's tail chooses it by the rows it has LEFT, as
     // launch_qqt its rows per block: r04, tools/r04_neutral_ab.sh, mixed-lengths leg 11.93 -> 12.11 k crops/s, ids bit-identical;
     // MOCR_NEUTRAL_BY_ROWS=0: by the batch's regime)
-    static const int neutral_by_rows = env_int("MOCR_NEUTRAL_BY_ROWS", 1);
+    static const int neutral_by_rows = env_int("MOCR_NEUTRAL_BY_ROWS", 2);
     if ((neutral_by_rows ? p.M : e->rrows(p.M)) < deep_rows && ktiles >= 4 && (long long)grid.x * grid.y * grid.z <= (long long)e->num_cus * (BM == 64 ? deep_mult64 : 1)) {
         hipLaunchKernelGGL((gemm_kernel<T, BM, BN, EPI, 4>), grid, dim3(256), 4 * (BM + BN) * 128, e->stream, p);
     } else {
@@ -870,6 +870,15 @@ static int dec_tile(int rows) {
     return rows >= fat ? 128 : 64;
 }
 
+// The tile a decode-step GEMM is LAUNCHED on: the tile size does not touch a sum (same K-tiles, same order; the split over K
+// stays the regime's, pick_split), so a compacted batch takes the tile of the rows it has left (MOCR_NEUTRAL_BY_ROWS >= 2, the
+// default; r04, tools/r04_neutral_ab.sh, mixed-lengths leg, by regime / ring depth + query blocks by rows / + tile by rows:
+// 11.96 / 12.12 / 12.39 k crops/s, ids bit-identical to the uncompacted engine in all three).
+static int dec_launch_tile(const mocr_engine* e, int rows) {
+    static const int neutral_by_rows = env_int("MOCR_NEUTRAL_BY_ROWS", 2);
+    return dec_tile(neutral_by_rows >= 2 ? rows : e->rrows(rows));
+}
+
 static int pick_split(int N, int K, int kt, int rows, long long slab_cap_per_row) {
     // Split K until ~`target` blocks cover the chip, bounded by the K-tiles and by the slab buffer.
     // Every extra slab is an fp32 [rows,N] write plus a read by the consumer, so fat batches
@@ -897,7 +906,7 @@ template <typename T>
 int dec_gemm(mocr_engine* e, const char* name, const void* A, int lda, const void* W, int N, int K, int rows) {
     const int kt = 128 / (int)sizeof(T);
     const int split = pick_split(N, K, kt, e->rrows(rows), e->slab_cap / e->Bp);
-    gemm<T>(e, name, A, lda, W, nullptr, e->slabs, N, nullptr, rows, N, K, EPI_SLAB, dec_tile(e->rrows(rows)), split, (long long)e->Bp * N);
+    gemm<T>(e, name, A, lda, W, nullptr, e->slabs, N, nullptr, rows, N, K, EPI_SLAB, dec_launch_tile(e, rows), split, (long long)e->Bp * N);
     return split;
 }
 
@@ -1120,7 +1129,7 @@ void latent_block(mocr_engine* e, bool self, int layer, int n, int t, const void
         q.wkT = reinterpret_cast<const bf16_t*>(wkT); q.qt = reinterpret_cast<bf16_t*>(e->qt);
         {
             ProfScope ps(e, "dec_qqt", 4.0 * n * D * D, (double)n * D * 2 + 2.0 * D * D * 2 + (double)n * e->H * D * 2);
-            static const int neutral_by_rows = env_int("MOCR_NEUTRAL_BY_ROWS", 1);
+            static const int neutral_by_rows = env_int("MOCR_NEUTRAL_BY_ROWS", 2);
             launch_qqt(e, q, n, neutral_by_rows ? n : e->rrows(n));
         }
         latent_attn(e, self, layer, n, self ? t + 1 : e->S);
@@ -1247,7 +1256,7 @@ void decode_step(mocr_engine* e, const DecState& st, int n, int t) {
         ns = dec_gemm<T>(e, "gemm_dec_proj", e->ctx_t, D, L.woc, D, D, n);
         dec_add_ln<T>(e, ns, D, L.boc, e->a_f32, L.ln2g, L.ln2b, e->c_f32, e->c_t, n, false);
         if (pick_split(F, D, 128 / (int)sizeof(T), rn, e->slab_cap / e->Bp) == 1) {
-            gemm<T>(e, "gemm_dec_fc1", e->c_t, D, L.w1, L.b1, e->h_t, F, nullptr, n, F, D, EPI_BIAS_GELU, dec_tile(rn), 1);
+            gemm<T>(e, "gemm_dec_fc1", e->c_t, D, L.w1, L.b1, e->h_t, F, nullptr, n, F, D, EPI_BIAS_GELU, dec_launch_tile(e, n), 1);
         } else {
             ns = dec_gemm<T>(e, "gemm_dec_fc1", e->c_t, D, L.w1, F, D, n);
             ProfScope ps(e, "dec_bias_gelu", 0, (double)n * F * (4.0 * ns + sizeof(T)));
@@ -1265,7 +1274,7 @@ void decode_step(mocr_engine* e, const DecState& st, int n, int t) {
     // LM head.  When the GEMM is not split over K and nobody asked for the logits, its epilogue reduces every N-tile
     // to (max, column) and the token kernel picks among V/tile candidates: the [n, V] fp32 logits (100 MB at 4096
     // rows) are neither written nor read.  acc + bias is the same fp32 value either way, so the argmax is identical.
-    const int vt = dec_tile(rn);
+    const int vt = dec_launch_tile(e, n);
     if (!st.logits_out && !(e->cfg.flags & MOCR_FLAG_NO_FUSED_ARGMAX) && (vt == 64 || vt == 128) &&
         pick_split(e->V, D, 128 / (int)sizeof(T), rn, e->slab_cap / e->Bp) == 1) {
         gemm<T>(e, "gemm_dec_vocab", e->z_t, D, w.wv, w.bv, e->cand_val, e->V, nullptr, n, e->V, D, EPI_ARGMAX, vt, 1, 0, nullptr, 0,
