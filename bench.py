@@ -222,8 +222,11 @@ def main():
         chunks = deal_sizes(args.queue, world, args.max_batch * args.lanes, policy=args.deal)
         steps_local = -(-max(b - a for a, b in chunks) // B)
         if use_dist:
-            from torch.distributed import distributed_c10d
-            store = distributed_c10d._get_default_store()
+            try:        # the process group's own store (rank 0's TCP store): `add` is an atomic fetch-and-add
+                from torch.distributed import distributed_c10d
+                store = distributed_c10d._get_default_store()
+            except (ImportError, AttributeError):       # a torch without that accessor: a store of our own next to the group's port
+                store = dist.TCPStore(os.environ["MASTER_ADDR"], int(os.environ.get("MASTER_PORT", "29500")) + 17, world, rank == 0)
     else:
         steps_local = 0
     # this rank's crops: global crop ids [rank*B, (rank+1)*B) of every step (weak); strong: every chunk replays the SAME B
